@@ -1,0 +1,273 @@
+/*
+ * rt_hip.h - C-ABI of the MI355X (gfx950) trace-and-shade library `librt_hip.so`.
+ *
+ * This is the drop-in boundary for the reference's raytrace.c (davidoguns/raytracer).
+ * Every declaration cites the reference interface it replaces as file:line relative to
+ * the reference tree.  Plain C: pointers and sizes only, no torch / C++ types.
+ *
+ * Layout contract: the POD types below are written from scratch but are byte-for-byte
+ * layout-compatible with the reference's x86-64 (SysV, non-Cell) structs, so that a host
+ * program compiled against the reference headers can hand its scene_t straight to
+ * raytrace() in this library.  Sizes/offsets are pinned by _Static_assert at the bottom.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------ */
+/* Reference-layout data types                                                          */
+/* ------------------------------------------------------------------------------------ */
+
+/* vector4_t / point_t  -- vector4.h:14-29 (16 B; w is carried but ignored by the math) */
+typedef struct { float x, y, z, w; } rt_vec4;
+
+/* color_t -- color.h:17-22 (12 B) */
+typedef struct { float r, g, b; } rt_color;
+
+/* plane_t -- plane.h:14-29: A*x + B*y + C*z + F = 0 (16 B) */
+typedef struct { float A, B, C, F; } rt_plane;
+
+/* sphere_t -- geometry.h:22-26 (20 B) */
+typedef struct { rt_vec4 center; float radius; } rt_sphere;
+
+/* polygon_t -- geometry.h:34-48 (32 B): plane + vertex list (host pointer) */
+typedef struct {
+    rt_plane  plane;
+    uint32_t  nVerticies;
+    rt_vec4  *vertex;
+} rt_polygon;
+
+/* material_t -- materials.h:24-34 (52 B); colors[0] = diffuse, colors[1] = specular */
+#define RT_MATERIAL_DIFFUSECOLOR  0
+#define RT_MATERIAL_SPECULARCOLOR 1
+typedef struct {
+    rt_color colors[2];
+    float    phong_ka, phong_kd, phong_ks, phong_ke;
+    float    kr, kt, n;
+} rt_material;
+
+/* geometry tags -- geometry.h:17-18 */
+#define RT_GEOMETRY_SPHERE  0x01
+#define RT_GEOMETRY_POLYGON 0x02
+
+/* object3d_t -- object3d.h:17-35, x86 variant with debugName (104 B) */
+typedef struct {
+    uint16_t    geometryType;
+    char       *debugName;
+    rt_material material;
+    union {
+        rt_sphere  sphr_obj;
+        rt_polygon poly_obj;
+    };
+} rt_object3d;
+
+/* pointlight_t -- light.h:17-26 (32 B); range is never read by the reference */
+typedef struct { rt_vec4 position; rt_color color; float range; } rt_pointlight;
+
+/* scene_t -- scene.h:22-64, non-SPU variant (184 B).  The seven view-plane fields are
+ * written by raytrace() exactly like the reference's prepare_scene (raytrace.c:72-85). */
+typedef struct {
+    rt_vec4        eyePos, lookAt, upVec;
+    rt_vec4        U, V, N;
+    uint32_t       frameBufferWidth, frameBufferHeight, sqrtSpp;
+    float          viewDistance, viewPlaneHalfWidth, viewPlaneHalfHeight, sppWidth;
+    rt_color       bgColor, ambientLightColor;
+    float          ldMax, lMax;
+    uint32_t       nLights, nObjects;
+    rt_pointlight *lights;
+    rt_object3d   *objects;
+} rt_scene_t;
+
+/* ------------------------------------------------------------------------------------ */
+/* north_star entry point types                                                         */
+/* ------------------------------------------------------------------------------------ */
+
+/* The part of scene_t the trace-and-shade loop reads (scene.h:39-40,45-46,58-59). */
+typedef struct {
+    rt_color             bgColor;
+    rt_color             ambientLightColor;
+    uint32_t             nLights;
+    uint32_t             nObjects;
+    const rt_pointlight *lights;    /* host pointer, nLights entries   */
+    const rt_object3d   *objects;   /* host pointer, nObjects entries  */
+} rt_scene;
+
+/* The reference has no camera type: camera = scene_t.{eyePos,U,V,N} (scene.h:24-29) + the
+ * view-plane fields prepare_scene fills (scene.h:31-37, raytrace.c:77-84) + MAX_DEPTH
+ * (raytrace.c:26,891). */
+typedef struct {
+    rt_vec4  eyePos, U, V, N;
+    uint32_t frameBufferWidth, frameBufferHeight, sqrtSpp;
+    float    viewDistance, viewPlaneHalfWidth, viewPlaneHalfHeight, sppWidth;
+    uint32_t depth;
+} rt_camera;
+
+/* Caller-owned frame buffer.  argb[x + y*width] = 0xFFRRGGBB, row 0 = top
+ * (raytrace.c:783-790, pam_output/output.c:25-27).  radiance (optional, may be NULL) receives
+ * the un-quantised per-pixel colour (the reference's internal colorbuffer, raytrace.c:887)
+ * as 3 floats per pixel.  Only rows [row0, row0+nrows) are rendered and written; both
+ * arrays are indexed with full-frame coordinates. */
+typedef struct {
+    uint32_t *argb;
+    float    *radiance;
+    uint32_t  width, height;
+    uint32_t  row0, nrows;
+} rt_framebuffer;
+
+/* Ray / work counters of the last render (deterministic functions of scene + camera). */
+typedef struct {
+    uint64_t primary_rays;      /* W*nrows*sqrtSpp^2                  raytrace.c:746-772 */
+    uint64_t shadow_rays;       /* one per shade node per light       raytrace.c:327-335 */
+    uint64_t reflection_rays;   /*                                    raytrace.c:405-431 */
+    uint64_t transmission_rays; /* refracted + total-internal-refl.   raytrace.c:452-539 */
+    uint64_t shade_nodes;       /* calls of get_shade_color_phong     raytrace.c:282     */
+    uint64_t tree_nodes;        /* shade nodes that spawned children (stored in HBM)     */
+    uint64_t queued_rays;       /* secondary rays that went through the HBM ray queues   */
+    uint32_t batches;           /* image batches the render was split into               */
+    uint32_t overflow_retries;  /* batches redone because a queue overflowed             */
+    /* algorithmic work, filled only by rt_hip_render_stats (instrumented kernels):       */
+    uint64_t sphere_tests, sphere_hits;
+    uint64_t polygon_tests, polygon_rej_parallel, polygon_rej_behind, polygon_full, polygon_hits;
+    uint64_t lights_lit;        /* (node, light) pairs that passed shadow + facing tests */
+    uint64_t nodes_sphere, nodes_polygon;
+    /* the same, restricted to the fused primary kernel (the dominant kernel):            */
+    uint64_t k0_sphere_tests, k0_sphere_hits;
+    uint64_t k0_polygon_tests, k0_polygon_rej_parallel, k0_polygon_rej_behind, k0_polygon_full;
+    uint64_t k0_shade_nodes, k0_nodes_sphere, k0_nodes_polygon, k0_lights_lit;
+    uint64_t k0_shadow_rays, k0_reflection_rays, k0_transmission_rays;
+    /* device time of the fused primary kernel, HIP events on the render stream (ms),
+     * summed over batches; 0 unless timing was enabled with rt_hip_ctx_set_timing.        */
+    float    k0_ms;
+    uint32_t k0_launches;
+} rt_hip_stats;
+
+/* ------------------------------------------------------------------------------------ */
+/* Entry points                                                                         */
+/* ------------------------------------------------------------------------------------ */
+
+/* Drop-in for the reference's render entry -- raytrace.h:17-20 / raytrace.c:874-931, sole
+ * call site main.c:159-160.  Same argument meaning; mutates *scene like prepare_scene
+ * (raytrace.c:894); blocking; on a HIP failure prints to stderr and exit(1) (the reference
+ * has no error channel: void return, main.c:153-157 style).  farZ is ignored (as in the
+ * reference). */
+void raytrace(unsigned int *buffer, rt_scene_t *scene,
+              float fovY, float aspectRatio, float nearZ, float farZ,
+              unsigned int width, unsigned int height,
+              unsigned int samplesPerPixelSq, unsigned int depth);
+
+/* north_star entry: render `fb` rows of `scene` seen through `camera` on the current HIP
+ * device.  Host pointers in, host pixels out (H2D of the flattened scene, kernels, D2H).
+ * Replaces the body of raytrace() after prepare_scene (raytrace.c:903-927).
+ * Returns 0 or a negative hipError_t / RT_E_* code. */
+int rt_hip_render(const rt_scene *scene, const rt_camera *camera, rt_framebuffer *fb);
+
+/* prepare_scene -- raytrace.c:72-85: fills the view-plane fields of *cam from the
+ * projection parameters (double-precision tan, stored to float), copies eye/U/V/N. */
+void rt_camera_prepare(rt_camera *cam, const rt_scene_t *scene,
+                       unsigned int width, unsigned int height, unsigned int sqrtSpp,
+                       float fovY, float aspectRatio, float nearZ, unsigned int depth);
+
+/* ---- device-resident interface (what bench.py and the multi-GPU host use) ----------- */
+
+typedef struct rt_hip_ctx rt_hip_ctx;
+
+#define RT_E_INVALID   (-10001)   /* bad argument                                   */
+#define RT_E_OVERFLOW  (-10002)   /* ray/node queue overflow even at 1-row batches  */
+#define RT_E_NOSCENE   (-10003)   /* render before rt_hip_scene_upload              */
+
+/* Create a render context on HIP device `device` (-1 = current).  max_queue_rays = capacity
+ * of each per-level ray queue and of the node pool (0 = default 32 Mi entries). */
+int  rt_hip_ctx_create(rt_hip_ctx **out, int device, uint64_t max_queue_rays);
+void rt_hip_ctx_destroy(rt_hip_ctx *ctx);
+
+/* Flatten the AoS host scene (object3d_t[], pointlight_t[], polygon vertex lists --
+ * the arrays the Cell build DMAs in spu/spu_main.c:54-148) into SoA device arrays. */
+int  rt_hip_scene_upload(rt_hip_ctx *ctx, const rt_scene *scene);
+
+/* Enqueue the render of rows [row0,row0+nrows) on `stream` (a hipStream_t, NULL = default
+ * stream).  d_argb / d_radiance are DEVICE pointers indexed with full-frame coordinates
+ * (d_radiance may be NULL).  Asynchronous with respect to the host. */
+int  rt_hip_render_rows(rt_hip_ctx *ctx, const rt_camera *camera,
+                        uint32_t *d_argb, float *d_radiance,
+                        uint32_t row0, uint32_t nrows, void *stream);
+
+/* Wait for the last rt_hip_render_rows, verify no queue overflowed (re-rendering finer
+ * batches if one did) and return its counters.  stats may be NULL. */
+int  rt_hip_finish(rt_hip_ctx *ctx, rt_hip_stats *stats);
+
+/* Same render with instrumented kernels that also count ray-object tests by outcome
+ * (for the algorithmic-FLOP numerator of the roofline).  Blocking. */
+int  rt_hip_render_stats(rt_hip_ctx *ctx, const rt_camera *camera,
+                         uint32_t *d_argb, float *d_radiance,
+                         uint32_t row0, uint32_t nrows, void *stream, rt_hip_stats *stats);
+
+/* Bracket the fused primary kernel with HIP events on the render stream (k0_ms). */
+void rt_hip_ctx_set_timing(rt_hip_ctx *ctx, int enable);
+/* Cap on primary samples per image batch (0 = automatic). */
+void rt_hip_ctx_set_batch_samples(rt_hip_ctx *ctx, uint64_t max_samples);
+
+const char *rt_hip_last_error(void);
+const char *rt_hip_version(void);
+
+/* ---- host-side scene helpers (reference scene.c / geometry.c equivalents) ---------- */
+
+/* poly_plane -- geometry.c:14-34 (normal from the first three vertices, F forced >= 0). */
+void rt_poly_plane(rt_plane *planeout, const rt_polygon *poly);
+
+/* The hard-coded Whitted scene that parse_scene always produces -- scene.c:86-258.
+ * Allocates lights/objects/vertices with malloc; release with rt_scene_free (scene.c:284). */
+int  rt_scene_builtin(rt_scene_t *scene);
+/* parse_scene -- scene.c:24-281: opens `filename` (error if unreadable, like scene.c:31-35),
+ * ignores its contents exactly as the reference does, and fills in the builtin scene.
+ * Returns 1 on success, 0 on failure (reference convention). */
+int  rt_parse_scene(const char *filename, rt_scene_t *scene);
+void rt_scene_free(rt_scene_t *scene);
+
+/* Seeded synthetic scenes of BASELINE configs 4/5: nSpheres random
+ * spheres + nPolys (0..4) axis-aligned quads + nLights lights; SplitMix64 generator.
+ * kind 0: config-4 distribution, kind 1: config-5 distribution. */
+int  rt_scene_synthetic(rt_scene_t *scene, uint64_t seed, uint32_t nSpheres,
+                        uint32_t nPolys, uint32_t nLights, int kind);
+
+/* write_image -- output.h:15-16 / pam_output/output.c:30-71: raw P6 "P6\n<W> <H>\n255\n"
+ * + RGB bytes, row 0 first.  Returns 1 on success, 0 on failure. */
+int  rt_write_image(const char *filename, const unsigned int *buffer,
+                    unsigned int width, unsigned int height);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+/* ---- layout pins (measured on the compiled reference) ------- */
+#if defined(__cplusplus)
+#define RT_SA(c, m) static_assert(c, m)
+#else
+#define RT_SA(c, m) _Static_assert(c, m)
+#endif
+RT_SA(sizeof(rt_vec4) == 16, "vector4_t");
+RT_SA(sizeof(rt_color) == 12, "color_t");
+RT_SA(sizeof(rt_plane) == 16, "plane_t");
+RT_SA(sizeof(rt_sphere) == 20, "sphere_t");
+RT_SA(sizeof(rt_polygon) == 32 && offsetof(rt_polygon, nVerticies) == 16 &&
+      offsetof(rt_polygon, vertex) == 24, "polygon_t");
+RT_SA(sizeof(rt_material) == 52, "material_t");
+RT_SA(sizeof(rt_pointlight) == 32 && offsetof(rt_pointlight, color) == 16 &&
+      offsetof(rt_pointlight, range) == 28, "pointlight_t");
+RT_SA(sizeof(rt_object3d) == 104 && offsetof(rt_object3d, debugName) == 8 &&
+      offsetof(rt_object3d, material) == 16 && offsetof(rt_object3d, sphr_obj) == 72 &&
+      offsetof(rt_object3d, poly_obj) == 72, "object3d_t");
+RT_SA(sizeof(rt_scene_t) == 184 && offsetof(rt_scene_t, U) == 48 &&
+      offsetof(rt_scene_t, frameBufferWidth) == 96 && offsetof(rt_scene_t, sppWidth) == 120 &&
+      offsetof(rt_scene_t, bgColor) == 124 && offsetof(rt_scene_t, ambientLightColor) == 136 &&
+      offsetof(rt_scene_t, ldMax) == 148 && offsetof(rt_scene_t, nLights) == 156 &&
+      offsetof(rt_scene_t, nObjects) == 160 && offsetof(rt_scene_t, lights) == 168 &&
+      offsetof(rt_scene_t, objects) == 176, "scene_t");
+#undef RT_SA
+
+#endif /* RT_HIP_H */

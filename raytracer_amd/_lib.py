@@ -1,0 +1,86 @@
+"""Loader for the in-tree HIP shared library.  There is no CPU fallback: if librt_hip.so is
+missing the import fails loudly (build it with `python -c 'import __graft_entry__ as g; g.build()'`
+or `make -C raytracer_amd/csrc`)."""
+import ctypes as C
+import os
+
+from . import _abi as A
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+
+# every symbol include/rt_hip.h declares
+EXPORTS = [
+    "raytrace", "rt_hip_render", "rt_camera_prepare", "rt_hip_ctx_create", "rt_hip_ctx_destroy",
+    "rt_hip_scene_upload", "rt_hip_render_rows", "rt_hip_finish", "rt_hip_render_stats",
+    "rt_hip_ctx_set_timing", "rt_hip_ctx_set_batch_samples", "rt_hip_last_error", "rt_hip_version",
+    "rt_poly_plane", "rt_scene_builtin", "rt_parse_scene", "rt_scene_free", "rt_scene_synthetic",
+    "rt_write_image",
+]
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built. There is no CPU fallback; "
+            "run __graft_entry__.build() (hipcc --offload-arch=gfx950).")
+    try:  # share torch's HIP runtime (same SONAME) when torch is in the process
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the C-ABI itself
+        pass
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    u32, u64, f32, vp, i32 = C.c_uint32, C.c_uint64, C.c_float, C.c_void_p, C.c_int
+    P = C.POINTER
+    lib.raytrace.argtypes = [vp, P(A.rt_scene_t), f32, f32, f32, f32, C.c_uint, C.c_uint, C.c_uint, C.c_uint]
+    lib.raytrace.restype = None
+    lib.rt_hip_render.argtypes = [P(A.rt_scene), P(A.rt_camera), P(A.rt_framebuffer)]
+    lib.rt_hip_render.restype = i32
+    lib.rt_camera_prepare.argtypes = [P(A.rt_camera), P(A.rt_scene_t), C.c_uint, C.c_uint, C.c_uint, f32, f32, f32, C.c_uint]
+    lib.rt_camera_prepare.restype = None
+    lib.rt_hip_ctx_create.argtypes = [P(vp), i32, u64]
+    lib.rt_hip_ctx_create.restype = i32
+    lib.rt_hip_ctx_destroy.argtypes = [vp]
+    lib.rt_hip_ctx_destroy.restype = None
+    lib.rt_hip_scene_upload.argtypes = [vp, P(A.rt_scene)]
+    lib.rt_hip_scene_upload.restype = i32
+    lib.rt_hip_render_rows.argtypes = [vp, P(A.rt_camera), vp, vp, u32, u32, vp]
+    lib.rt_hip_render_rows.restype = i32
+    lib.rt_hip_finish.argtypes = [vp, P(A.rt_hip_stats)]
+    lib.rt_hip_finish.restype = i32
+    lib.rt_hip_render_stats.argtypes = [vp, P(A.rt_camera), vp, vp, u32, u32, vp, P(A.rt_hip_stats)]
+    lib.rt_hip_render_stats.restype = i32
+    lib.rt_hip_ctx_set_timing.argtypes = [vp, i32]
+    lib.rt_hip_ctx_set_timing.restype = None
+    lib.rt_hip_ctx_set_batch_samples.argtypes = [vp, u64]
+    lib.rt_hip_ctx_set_batch_samples.restype = None
+    lib.rt_hip_last_error.restype = C.c_char_p
+    lib.rt_hip_version.restype = C.c_char_p
+    lib.rt_poly_plane.argtypes = [P(A.rt_plane), P(A.rt_polygon)]
+    lib.rt_poly_plane.restype = None
+    lib.rt_scene_builtin.argtypes = [P(A.rt_scene_t)]
+    lib.rt_scene_builtin.restype = i32
+    lib.rt_parse_scene.argtypes = [C.c_char_p, P(A.rt_scene_t)]
+    lib.rt_parse_scene.restype = i32
+    lib.rt_scene_free.argtypes = [P(A.rt_scene_t)]
+    lib.rt_scene_free.restype = None
+    lib.rt_scene_synthetic.argtypes = [P(A.rt_scene_t), u64, u32, u32, u32, i32]
+    lib.rt_scene_synthetic.restype = i32
+    lib.rt_write_image.argtypes = [C.c_char_p, vp, C.c_uint, C.c_uint]
+    lib.rt_write_image.restype = i32
+    _lib = lib
+    return lib
+
+
+class RtHipError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().rt_hip_last_error().decode(errors="replace")
+        raise RtHipError(f"{what} failed with code {rc}: {msg}")

@@ -1,0 +1,159 @@
+"""Host-side mirror of the reference's interface for the trace-and-shade path.
+
+Names follow the reference: parse_scene / free_scene (scene.h:67-70), raytrace (raytrace.h:17-20),
+write_image (output.h:15-16).  Everything computes through librt_hip.so (HIP kernels); nothing
+here renders on the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi as A
+from ._lib import RtHipError, check, load
+
+
+class Scene:
+    """Owns an rt_scene_t (the reference's scene_t) built by the library's host helpers."""
+
+    def __init__(self):
+        self.c = A.rt_scene_t()
+        self._owned = False
+
+    @classmethod
+    def builtin(cls):
+        s = cls()
+        if not load().rt_scene_builtin(C.byref(s.c)):
+            raise MemoryError("rt_scene_builtin")
+        s._owned = True
+        return s
+
+    @classmethod
+    def synthetic(cls, seed, n_spheres, n_polys=4, n_lights=1, kind=0):
+        s = cls()
+        if not load().rt_scene_synthetic(C.byref(s.c), seed, n_spheres, n_polys, n_lights, kind):
+            raise ValueError("rt_scene_synthetic: bad arguments")
+        s._owned = True
+        return s
+
+    def view(self):
+        return A.scene_view(self.c)
+
+    def free(self):
+        if self._owned:
+            load().rt_scene_free(C.byref(self.c))
+            self._owned = False
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def parse_scene(filename):
+    """scene.c:24 - returns a Scene (the reference ignores the file's contents) or raises."""
+    s = Scene()
+    if not load().rt_parse_scene(str(filename).encode(), C.byref(s.c)):
+        raise OSError(f"Error opening file {{{filename}}} for reading.")
+    s._owned = True
+    return s
+
+
+def free_scene(scene):
+    scene.free()
+
+
+def prepare_camera(scene, width, height, sqrt_spp, depth, fov_y=45.0, aspect=None, near_z=1.0):
+    """prepare_scene raytrace.c:72-85 with main.c:159-160's projection defaults."""
+    cam = A.rt_camera()
+    if aspect is None:
+        aspect = np.float32(width) / np.float32(height)
+    load().rt_camera_prepare(C.byref(cam), C.byref(scene.c), width, height, sqrt_spp,
+                             float(fov_y), float(aspect), float(near_z), depth)
+    return cam
+
+
+def raytrace(buffer, scene, fovY, aspectRatio, nearZ, farZ, width, height, samplesPerPixelSq, depth):
+    """raytrace.h:17-20 - fills the caller's uint32 buffer (numpy, W*H) with 0xFFRRGGBB pixels."""
+    buf = np.ascontiguousarray(buffer, dtype=np.uint32)
+    if buf.size != width * height:
+        raise ValueError("buffer must hold width*height uint32 pixels")
+    load().raytrace(buf.ctypes.data, C.byref(scene.c), fovY, aspectRatio, nearZ, farZ, width, height,
+                    samplesPerPixelSq, depth)
+    if buf is not buffer:
+        np.copyto(buffer.reshape(-1), buf.reshape(-1))
+    return buffer
+
+
+def render(scene, cam, row0=0, nrows=None, want_radiance=True):
+    """rt_hip_render on host arrays: returns (argb[H,W] uint32, radiance[H,W,3] float32 or None)."""
+    W, H = cam.frameBufferWidth, cam.frameBufferHeight
+    if nrows is None:
+        nrows = H - row0
+    argb = np.zeros((H, W), dtype=np.uint32)
+    rad = np.zeros((H, W, 3), dtype=np.float32) if want_radiance else None
+    fb = A.rt_framebuffer()
+    fb.argb = argb.ctypes.data_as(C.POINTER(C.c_uint32))
+    fb.radiance = rad.ctypes.data_as(C.POINTER(C.c_float)) if want_radiance else None
+    fb.width, fb.height, fb.row0, fb.nrows = W, H, row0, nrows
+    view = scene.view()
+    check(load().rt_hip_render(C.byref(view), C.byref(cam), C.byref(fb)), "rt_hip_render")
+    return argb, rad
+
+
+def write_image(filename, buffer, width, height):
+    """output.h:15-16 - raw P6; returns 1 on success, 0 on failure like the reference."""
+    buf = np.ascontiguousarray(buffer, dtype=np.uint32)
+    return load().rt_write_image(str(filename).encode(), buf.ctypes.data, width, height)
+
+
+class Context:
+    """Device-resident renderer: scene and frame buffer stay in HBM (bench / multi-GPU path)."""
+
+    def __init__(self, device=-1, queue_cap=0):
+        self._h = C.c_void_p()
+        check(load().rt_hip_ctx_create(C.byref(self._h), device, queue_cap), "rt_hip_ctx_create")
+
+    def upload(self, scene):
+        view = scene.view()
+        check(load().rt_hip_scene_upload(self._h, C.byref(view)), "rt_hip_scene_upload")
+
+    def set_timing(self, on):
+        load().rt_hip_ctx_set_timing(self._h, int(bool(on)))
+
+    def set_batch_samples(self, n):
+        load().rt_hip_ctx_set_batch_samples(self._h, int(n))
+
+    def render_rows(self, cam, d_argb, d_radiance=0, row0=0, nrows=None, stream=0):
+        if nrows is None:
+            nrows = cam.frameBufferHeight - row0
+        check(load().rt_hip_render_rows(self._h, C.byref(cam), d_argb, d_radiance or None, row0, nrows,
+                                        stream or None), "rt_hip_render_rows")
+
+    def finish(self):
+        st = A.rt_hip_stats()
+        check(load().rt_hip_finish(self._h, C.byref(st)), "rt_hip_finish")
+        return st
+
+    def render_stats(self, cam, d_argb, d_radiance=0, row0=0, nrows=None, stream=0):
+        if nrows is None:
+            nrows = cam.frameBufferHeight - row0
+        st = A.rt_hip_stats()
+        check(load().rt_hip_render_stats(self._h, C.byref(cam), d_argb, d_radiance or None, row0, nrows,
+                                         stream or None, C.byref(st)), "rt_hip_render_stats")
+        return st
+
+    def close(self):
+        if self._h:
+            load().rt_hip_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+__all__ = ["Scene", "Context", "parse_scene", "free_scene", "prepare_camera", "raytrace", "render",
+           "write_image", "RtHipError"]

@@ -1,0 +1,774 @@
+/*
+ * rt_api.hip - C-ABI of librt_hip.so (include/rt_hip.h): render contexts, AoS -> SoA scene
+ * flattening, the per-batch launch sequence, overflow recovery, and the reference-signature
+ * raytrace() entry point.  Host code only; kernels live in rt_kernels.hip.
+ */
+#include "rt_device.h"
+#include "rt_hip.h"
+
+#include <mutex>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+void set_err(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return -(int)e_;                                                                  \
+        }                                                                                     \
+    } while (0)
+
+constexpr uint32_t kMaxBatches = 1024;          /* counter slots per enqueue round */
+constexpr uint64_t kDefaultCap = 64ull << 20;   /* entries per queue / node pool   */
+
+struct Batch {
+    uint32_t y0, y1;
+    uint32_t slot;
+};
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+} // namespace
+
+struct rt_hip_ctx {
+    int device = 0;
+    uint64_t cap = 0;
+    /* scene */
+    bool have_scene = false;
+    DevScene S{};
+    void *scene_blob = nullptr;
+    /* work buffers */
+    void *work_blob = nullptr;
+    DevWork W{};
+    float4 *pixAcc = nullptr;
+    size_t pix_cap = 0;
+    uint32_t *d_counters = nullptr; /* [kMaxBatches][RT_COUNTER_WORDS] */
+    uint32_t *h_counters = nullptr; /* pinned mirror */
+    /* pending render */
+    bool pending = false;
+    bool pending_stats = false;
+    rt_camera cam{};
+    DevCamera C{};
+    uint32_t *d_argb = nullptr;
+    float *d_rad = nullptr;
+    uint32_t row0 = 0, nrows = 0;
+    hipStream_t stream = nullptr;
+    std::vector<Batch> batches;
+    /* options */
+    bool timing = false;
+    uint64_t batch_samples = 0;
+    std::vector<hipEvent_t> ev; /* 2 per batch when timing */
+    rt_hip_stats stats{};
+};
+
+namespace {
+
+int ctx_set_device(rt_hip_ctx *c)
+{
+    HIP_TRY(hipSetDevice(c->device));
+    return 0;
+}
+
+/* raytrace.c:737,751 + the pixel-independent pieces of :755-763, with the reference's float
+ * rounding (this file is compiled with -ffp-contract=off) */
+void fold_camera(DevCamera &C, const rt_camera &cam)
+{
+    const float e[3] = {cam.eyePos.x, cam.eyePos.y, cam.eyePos.z};
+    const float U[3] = {cam.U.x, cam.U.y, cam.U.z};
+    const float V[3] = {cam.V.x, cam.V.y, cam.V.z};
+    const float N[3] = {cam.N.x, cam.N.y, cam.N.z};
+    for (int k = 0; k < 3; ++k) {
+        C.eye[k] = e[k];
+        C.U[k] = U[k];
+        C.V[k] = V[k];
+        C.shiftN[k] = N[k] * cam.viewDistance;
+    }
+    C.halfW = cam.viewPlaneHalfWidth;
+    C.halfH = cam.viewPlaneHalfHeight;
+    C.hfbW = (float)cam.frameBufferWidth / 2.0f;
+    C.hfbH = (float)cam.frameBufferHeight / 2.0f;
+    C.sppW = cam.sppWidth;
+    C.sppHalf = cam.sppWidth / 2.0f;
+    C.scale = 1.0f / (float)(cam.sqrtSpp * cam.sqrtSpp);
+    C.W = cam.frameBufferWidth;
+    C.H = cam.frameBufferHeight;
+    C.sqrtSpp = cam.sqrtSpp;
+    C.depth = cam.depth;
+}
+
+int ensure_pix(rt_hip_ctx *c, size_t npix)
+{
+    if (npix <= c->pix_cap)
+        return 0;
+    if (c->pixAcc)
+        HIP_TRY(hipFree(c->pixAcc));
+    c->pixAcc = nullptr;
+    c->pix_cap = 0;
+    HIP_TRY(hipMalloc((void **)&c->pixAcc, npix * sizeof(float4)));
+    c->pix_cap = npix;
+    return 0;
+}
+
+/* enqueue one image batch: rows [y0,y1) */
+int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
+{
+    DevWork Wk = c->W;
+    Wk.pixAcc = c->pixAcc;
+    Wk.counters = c->d_counters + (size_t)b.slot * RT_COUNTER_WORDS;
+    hipStream_t st = c->stream;
+    HIP_TRY(hipMemsetAsync(Wk.counters, 0, RT_COUNTER_WORDS * sizeof(uint32_t), st));
+    const bool timed = c->timing && !stats;
+    if (timed) {
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        c->ev.push_back(e0);
+        c->ev.push_back(e1);
+        HIP_TRY(hipEventRecord(e0, st));
+    }
+    rt_launch_primary(c->S, c->C, Wk, b.y0, b.y1, stats, st);
+    if (timed)
+        HIP_TRY(hipEventRecord(c->ev.back(), st));
+    const uint32_t depth = c->C.depth;
+    for (uint32_t d = 1; d <= depth; ++d)
+        rt_launch_bounce(c->S, c->C, Wk, d, stats, st);
+    for (uint32_t d = depth; d-- > 1;) /* nodes exist on levels 0..depth-1; level 0 folds in resolve */
+        rt_launch_fold(Wk, d, st);
+    rt_launch_resolve(c->C, Wk, b.y0, b.y1, c->d_argb, c->d_rad, st);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+uint32_t rows_per_batch(const rt_hip_ctx *c, uint64_t max_samples)
+{
+    const uint64_t per_row = (uint64_t)c->C.W * c->C.sqrtSpp * c->C.sqrtSpp;
+    uint64_t rows = per_row ? max_samples / per_row : 1;
+    if (rows >= 8)
+        rows -= rows % 8; /* keep 8-row wave tiles whole */
+    if (rows < 1)
+        rows = 1;
+    return (uint32_t)(rows > 0xFFFFFFFFull ? 0xFFFFFFFFull : rows);
+}
+
+void accumulate(rt_hip_stats &s, const uint32_t *cnt)
+{
+    const uint64_t *st = (const uint64_t *)(cnt + CNT_STATS64);
+    for (int l = 0; l < RT_MAX_LEVELS; ++l) {
+        s.queued_rays += cnt[CNT_QCOUNT + l];
+        s.tree_nodes += cnt[CNT_NCOUNT + l];
+    }
+    s.shade_nodes += st[ST_K0_SHADE_NODES] + st[ST_KB_SHADE_NODES];
+    s.reflection_rays += st[ST_K0_REFL] + st[ST_KB_REFL];
+    s.transmission_rays += st[ST_K0_TRANS] + st[ST_KB_TRANS];
+    s.k0_shade_nodes += st[ST_K0_SHADE_NODES];
+    s.k0_reflection_rays += st[ST_K0_REFL];
+    s.k0_transmission_rays += st[ST_K0_TRANS];
+    s.sphere_tests += st[ST_SPH_TESTS];
+    s.sphere_hits += st[ST_SPH_HITS];
+    s.polygon_tests += st[ST_POLY_TESTS];
+    s.polygon_rej_parallel += st[ST_POLY_PAR];
+    s.polygon_rej_behind += st[ST_POLY_BEHIND];
+    s.polygon_full += st[ST_POLY_FULL];
+    s.polygon_hits += st[ST_POLY_HITS];
+    s.lights_lit += st[ST_LIT];
+    s.nodes_sphere += st[ST_NODES_SPH];
+    s.nodes_polygon += st[ST_NODES_POLY];
+    s.k0_sphere_tests += st[ST_K0_SPH_TESTS];
+    s.k0_sphere_hits += st[ST_K0_SPH_HITS];
+    s.k0_polygon_tests += st[ST_K0_POLY_TESTS];
+    s.k0_polygon_rej_parallel += st[ST_K0_POLY_PAR];
+    s.k0_polygon_rej_behind += st[ST_K0_POLY_BEHIND];
+    s.k0_polygon_full += st[ST_K0_POLY_FULL];
+    s.k0_lights_lit += st[ST_K0_LIT];
+    s.k0_nodes_sphere += st[ST_K0_NODES_SPH];
+    s.k0_nodes_polygon += st[ST_K0_NODES_POLY];
+}
+
+/* Render rows [y0,y1) in batches of `rows` rows, wait, and re-render (halving the batch height)
+ * every batch whose queues overflowed.  Adds the counters of the good batches to c->stats. */
+int render_range_sync(rt_hip_ctx *c, uint32_t y0, uint32_t y1, uint32_t rows, bool stats)
+{
+    std::vector<Batch> todo;
+    for (uint32_t y = y0; y < y1;) {
+        const uint32_t ye = (y1 - y > rows) ? y + rows : y1;
+        todo.push_back({y, ye, 0});
+        y = ye;
+    }
+    size_t done = 0;
+    while (done < todo.size()) {
+        const size_t n = std::min<size_t>(todo.size() - done, kMaxBatches);
+        for (size_t i = 0; i < n; ++i) {
+            todo[done + i].slot = (uint32_t)i;
+            int rc = enqueue_batch(c, todo[done + i], stats);
+            if (rc)
+                return rc;
+        }
+        HIP_TRY(hipMemcpyAsync(c->h_counters, c->d_counters, n * RT_COUNTER_WORDS * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (size_t i = 0; i < n; ++i) {
+            const Batch &b = todo[done + i];
+            const uint32_t *cnt = c->h_counters + i * RT_COUNTER_WORDS;
+            if (cnt[CNT_OVERFLOW]) {
+                const uint32_t h = b.y1 - b.y0;
+                if (h <= 1) {
+                    set_err("ray/node queues (%llu entries) overflow on a single row; raise the capacity",
+                            (unsigned long long)c->cap);
+                    return RT_E_OVERFLOW;
+                }
+                c->stats.overflow_retries++;
+                /* cannot recurse while h_counters of this round is still being read: copy first */
+                std::vector<uint32_t> keep(c->h_counters, c->h_counters + n * RT_COUNTER_WORDS);
+                int rc = render_range_sync(c, b.y0, b.y1, (h + 1) / 2, stats);
+                memcpy(c->h_counters, keep.data(), keep.size() * sizeof(uint32_t));
+                if (rc)
+                    return rc;
+            } else {
+                accumulate(c->stats, cnt);
+                c->stats.batches++;
+            }
+        }
+        done += n;
+    }
+    return 0;
+}
+
+void finish_stats(rt_hip_ctx *c)
+{
+    rt_hip_stats &s = c->stats;
+    s.primary_rays = (uint64_t)c->C.W * c->nrows * c->C.sqrtSpp * c->C.sqrtSpp;
+    s.shadow_rays = s.shade_nodes * c->S.nLights;
+    s.k0_shadow_rays = s.k0_shade_nodes * c->S.nLights;
+}
+
+int check_args(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb, uint32_t row0, uint32_t nrows)
+{
+    if (!c || !cam || !d_argb) {
+        set_err("null argument");
+        return RT_E_INVALID;
+    }
+    if (!c->have_scene) {
+        set_err("no scene uploaded");
+        return RT_E_NOSCENE;
+    }
+    if (cam->frameBufferWidth == 0 || cam->frameBufferHeight == 0 || cam->sqrtSpp == 0) {
+        set_err("empty frame or zero samples per pixel");
+        return RT_E_INVALID;
+    }
+    if (cam->depth > RT_MAX_LEVELS - 2) {
+        set_err("depth %u exceeds the supported maximum %d", cam->depth, RT_MAX_LEVELS - 2);
+        return RT_E_INVALID;
+    }
+    if ((uint64_t)row0 + nrows > cam->frameBufferHeight) {
+        set_err("rows [%u,%u) outside the %u-row frame", row0, row0 + nrows, cam->frameBufferHeight);
+        return RT_E_INVALID;
+    }
+    if ((uint64_t)cam->sqrtSpp * cam->sqrtSpp > 0xFFFFu) {
+        set_err("sqrtSpp too large");
+        return RT_E_INVALID;
+    }
+    return 0;
+}
+
+uint64_t default_batch_samples(const rt_hip_ctx *c)
+{
+    /* every sample can become one root node and two level-1 rays */
+    uint64_t m = c->cap / 2;
+    if (c->batch_samples && c->batch_samples < m)
+        m = c->batch_samples;
+    return m ? m : 1;
+}
+
+void drop_events(rt_hip_ctx *c)
+{
+    for (hipEvent_t e : c->ev)
+        (void)hipEventDestroy(e);
+    c->ev.clear();
+}
+
+} // namespace
+
+extern "C" {
+
+const char *rt_hip_last_error(void) { return g_err; }
+const char *rt_hip_version(void) { return "rt_hip 0.1 (gfx950)"; }
+
+int rt_hip_ctx_create(rt_hip_ctx **out, int device, uint64_t max_queue_rays)
+{
+    if (!out) {
+        set_err("null argument");
+        return RT_E_INVALID;
+    }
+    *out = nullptr;
+    if (device < 0)
+        HIP_TRY(hipGetDevice(&device));
+    rt_hip_ctx *c = new rt_hip_ctx();
+    c->device = device;
+    uint64_t cap = max_queue_rays;
+    if (!cap) {
+        const char *env = getenv("RT_HIP_QUEUE_CAP");
+        cap = env ? strtoull(env, nullptr, 0) : 0;
+        if (!cap)
+            cap = kDefaultCap;
+    }
+    if (cap < 1024)
+        cap = 1024;
+    if (cap > (1ull << 28))
+        cap = 1ull << 28; /* node links are 29-bit, ray parents 31-bit */
+    c->cap = cap;
+    int rc = ctx_set_device(c);
+    if (rc) {
+        delete c;
+        return rc;
+    }
+    /* one blob: 4 queue arrays + 3 node arrays of cap float4 each */
+    const size_t arr = align_up(cap * sizeof(float4), 256);
+    hipError_t e = hipMalloc(&c->work_blob, arr * 7);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&c->d_counters, (size_t)kMaxBatches * RT_COUNTER_WORDS * sizeof(uint32_t));
+    if (e == hipSuccess)
+        e = hipHostMalloc((void **)&c->h_counters, (size_t)kMaxBatches * RT_COUNTER_WORDS * sizeof(uint32_t),
+                          hipHostMallocDefault);
+    if (e != hipSuccess) {
+        set_err("allocating %zu bytes of queue memory failed: %s", arr * 7, hipGetErrorString(e));
+        rt_hip_ctx_destroy(c);
+        return -(int)e;
+    }
+    char *p = (char *)c->work_blob;
+    c->W.qA[0] = (float4 *)(p + 0 * arr);
+    c->W.qB[0] = (float4 *)(p + 1 * arr);
+    c->W.qA[1] = (float4 *)(p + 2 * arr);
+    c->W.qB[1] = (float4 *)(p + 3 * arr);
+    c->W.nodeA = (float4 *)(p + 4 * arr);
+    c->W.nodeB = (float4 *)(p + 5 * arr);
+    c->W.nodeC = (float4 *)(p + 6 * arr);
+    c->W.cap = (uint32_t)cap;
+    *out = c;
+    return 0;
+}
+
+void rt_hip_ctx_destroy(rt_hip_ctx *c)
+{
+    if (!c)
+        return;
+    (void)hipSetDevice(c->device);
+    if (c->pending && c->stream)
+        (void)hipStreamSynchronize(c->stream);
+    drop_events(c);
+    if (c->scene_blob) (void)hipFree(c->scene_blob);
+    if (c->work_blob) (void)hipFree(c->work_blob);
+    if (c->pixAcc) (void)hipFree(c->pixAcc);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->h_counters) (void)hipHostFree(c->h_counters);
+    delete c;
+}
+
+void rt_hip_ctx_set_timing(rt_hip_ctx *c, int enable)
+{
+    if (c)
+        c->timing = enable != 0;
+}
+
+void rt_hip_ctx_set_batch_samples(rt_hip_ctx *c, uint64_t max_samples)
+{
+    if (c)
+        c->batch_samples = max_samples;
+}
+
+int rt_hip_scene_upload(rt_hip_ctx *c, const rt_scene *sc)
+{
+    if (!c || !sc || (sc->nObjects && !sc->objects) || (sc->nLights && !sc->lights)) {
+        set_err("null argument");
+        return RT_E_INVALID;
+    }
+    int rc = ctx_set_device(c);
+    if (rc)
+        return rc;
+    if (c->pending) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->pending = false;
+    }
+
+    const uint32_t nObj = sc->nObjects, nL = sc->nLights;
+    std::vector<float4> sph, planes, infos, verts;
+    std::vector<uint32_t> sph_obj;
+    std::vector<float4> oA(nObj), oB(nObj), oC(nObj), oD(nObj), oE(nObj);
+    for (uint32_t i = 0; i < nObj; ++i) {
+        const rt_object3d &o = sc->objects[i];
+        const rt_material &m = o.material;
+        const rt_color &df = m.colors[RT_MATERIAL_DIFFUSECOLOR], &sp = m.colors[RT_MATERIAL_SPECULARCOLOR];
+        oA[i] = make_float4(df.r, df.g, df.b, m.phong_ka);
+        oB[i] = make_float4(sp.r, sp.g, sp.b, m.phong_ks);
+        oC[i] = make_float4(m.phong_kd, m.phong_ke, m.kr, m.kt);
+        uint32_t glist = RT_NONE;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (o.geometryType == RT_GEOMETRY_SPHERE) {
+            const rt_sphere &s = o.sphr_obj;
+            glist = (uint32_t)sph.size();
+            /* radius*radius is the same float product the reference forms per test (ray.c:194) */
+            sph.push_back(make_float4(s.center.x, s.center.y, s.center.z, s.radius * s.radius));
+            sph_obj.push_back(i);
+            g = make_float4(s.center.x, s.center.y, s.center.z, 0.f);
+        } else if (o.geometryType == RT_GEOMETRY_POLYGON) {
+            const rt_polygon &pg = o.poly_obj;
+            if (pg.nVerticies == 0 || !pg.vertex) {
+                set_err("polygon object %u has no vertices", i);
+                return RT_E_INVALID;
+            }
+            glist = (uint32_t)planes.size();
+            planes.push_back(make_float4(pg.plane.A, pg.plane.B, pg.plane.C, pg.plane.F));
+            float4 info;
+            info.x = __builtin_bit_cast(float, (uint32_t)verts.size());
+            info.y = __builtin_bit_cast(float, (uint32_t)pg.nVerticies);
+            info.z = __builtin_bit_cast(float, i);
+            info.w = 0.f;
+            infos.push_back(info);
+            for (uint32_t v = 0; v < pg.nVerticies; ++v)
+                verts.push_back(make_float4(pg.vertex[v].x, pg.vertex[v].y, pg.vertex[v].z, pg.vertex[v].w));
+            g = make_float4(pg.plane.A, pg.plane.B, pg.plane.C, 0.f);
+        } /* any other tag never intersects (raytrace.c:179-180): it keeps its index, no geometry */
+        oD[i] = make_float4(m.n, __builtin_bit_cast(float, (uint32_t)o.geometryType),
+                            __builtin_bit_cast(float, glist), 0.f);
+        oE[i] = g;
+    }
+    const uint32_t nSph = (uint32_t)sph.size(), nPoly = (uint32_t)planes.size();
+    const size_t polySlots = 2 * (size_t)nPoly + verts.size();
+    if (polySlots > RT_MAX_POLY_LDS) {
+        set_err("polygon data needs %zu LDS slots, limit is %d", polySlots, RT_MAX_POLY_LDS);
+        return RT_E_INVALID;
+    }
+    std::vector<float4> poly;
+    poly.insert(poly.end(), planes.begin(), planes.end());
+    poly.insert(poly.end(), infos.begin(), infos.end());
+    poly.insert(poly.end(), verts.begin(), verts.end());
+    std::vector<float4> lp(nL), lc(nL);
+    for (uint32_t l = 0; l < nL; ++l) {
+        const rt_pointlight &L = sc->lights[l];
+        lp[l] = make_float4(L.position.x, L.position.y, L.position.z, L.position.w);
+        lc[l] = make_float4(L.color.r, L.color.g, L.color.b, 0.f);
+    }
+
+    /* one blob, 256-B aligned arrays */
+    struct Seg { const void *src; size_t bytes; size_t off; };
+    Seg segs[10] = {
+        {sph.data(), sph.size() * sizeof(float4), 0},   {sph_obj.data(), sph_obj.size() * sizeof(uint32_t), 0},
+        {poly.data(), poly.size() * sizeof(float4), 0}, {oA.data(), oA.size() * sizeof(float4), 0},
+        {oB.data(), oB.size() * sizeof(float4), 0},     {oC.data(), oC.size() * sizeof(float4), 0},
+        {oD.data(), oD.size() * sizeof(float4), 0},     {oE.data(), oE.size() * sizeof(float4), 0},
+        {lp.data(), lp.size() * sizeof(float4), 0},     {lc.data(), lc.size() * sizeof(float4), 0}};
+    size_t total = 0;
+    for (Seg &s : segs) {
+        s.off = total;
+        total += align_up(s.bytes ? s.bytes : 16, 256);
+    }
+    std::vector<char> host(total, 0);
+    for (const Seg &s : segs)
+        if (s.bytes)
+            memcpy(host.data() + s.off, s.src, s.bytes);
+    if (c->scene_blob) {
+        HIP_TRY(hipFree(c->scene_blob));
+        c->scene_blob = nullptr;
+        c->have_scene = false;
+    }
+    HIP_TRY(hipMalloc(&c->scene_blob, total));
+    HIP_TRY(hipMemcpy(c->scene_blob, host.data(), total, hipMemcpyHostToDevice));
+    char *b = (char *)c->scene_blob;
+    DevScene &S = c->S;
+    S.sph = (const float4 *)(b + segs[0].off);
+    S.sph_obj = (const uint32_t *)(b + segs[1].off);
+    S.poly = (const float4 *)(b + segs[2].off);
+    S.objA = (const float4 *)(b + segs[3].off);
+    S.objB = (const float4 *)(b + segs[4].off);
+    S.objC = (const float4 *)(b + segs[5].off);
+    S.objD = (const float4 *)(b + segs[6].off);
+    S.objE = (const float4 *)(b + segs[7].off);
+    S.light_pos = (const float4 *)(b + segs[8].off);
+    S.light_col = (const float4 *)(b + segs[9].off);
+    S.nSph = nSph;
+    S.nPoly = nPoly;
+    S.nPolySlots = (uint32_t)polySlots;
+    S.nObj = nObj;
+    S.nLights = nL;
+    S.bg[0] = sc->bgColor.r; S.bg[1] = sc->bgColor.g; S.bg[2] = sc->bgColor.b;
+    S.ambient[0] = sc->ambientLightColor.r;
+    S.ambient[1] = sc->ambientLightColor.g;
+    S.ambient[2] = sc->ambientLightColor.b;
+    c->have_scene = true;
+    return 0;
+}
+
+int rt_hip_render_rows(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb, float *d_rad,
+                       uint32_t row0, uint32_t nrows, void *stream)
+{
+    int rc = check_args(c, cam, d_argb, row0, nrows);
+    if (rc)
+        return rc;
+    rc = ctx_set_device(c);
+    if (rc)
+        return rc;
+    if (c->pending) { /* the previous render's counters were never collected: drain it */
+        rc = rt_hip_finish(c, nullptr);
+        if (rc)
+            return rc;
+    }
+    c->cam = *cam;
+    fold_camera(c->C, *cam);
+    c->d_argb = d_argb;
+    c->d_rad = d_rad;
+    c->row0 = row0;
+    c->nrows = nrows;
+    c->stream = (hipStream_t)stream;
+    c->pending_stats = false;
+    c->batches.clear();
+    drop_events(c);
+    memset(&c->stats, 0, sizeof c->stats);
+    if (nrows == 0) {
+        c->pending = true;
+        return 0;
+    }
+    const uint32_t rows = rows_per_batch(c, default_batch_samples(c));
+    const uint32_t brow = rows < nrows ? rows : nrows;
+    rc = ensure_pix(c, (size_t)brow * c->C.W);
+    if (rc)
+        return rc;
+    uint32_t slot = 0;
+    for (uint32_t y = row0; y < row0 + nrows;) {
+        const uint32_t ye = (row0 + nrows - y > rows) ? y + rows : row0 + nrows;
+        if (slot == kMaxBatches) { /* out of counter slots: collect what is queued so far */
+            set_err("render needs more than %u batches; raise the queue capacity", kMaxBatches);
+            return RT_E_INVALID;
+        }
+        Batch b{y, ye, slot++};
+        c->batches.push_back(b);
+        rc = enqueue_batch(c, b, false);
+        if (rc)
+            return rc;
+        y = ye;
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_counters, c->d_counters,
+                           c->batches.size() * RT_COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                           c->stream));
+    c->pending = true;
+    return 0;
+}
+
+int rt_hip_finish(rt_hip_ctx *c, rt_hip_stats *stats)
+{
+    if (!c) {
+        set_err("null argument");
+        return RT_E_INVALID;
+    }
+    if (!c->pending) {
+        if (stats)
+            *stats = c->stats;
+        return 0;
+    }
+    int rc = ctx_set_device(c);
+    if (rc)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->pending = false;
+    /* timing of the fused primary kernel */
+    for (size_t i = 0; i + 1 < c->ev.size(); i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess) {
+            c->stats.k0_ms += ms;
+            c->stats.k0_launches++;
+        }
+    }
+    drop_events(c);
+    std::vector<Batch> redo;
+    std::vector<uint32_t> snap(c->h_counters, c->h_counters + c->batches.size() * RT_COUNTER_WORDS);
+    for (size_t i = 0; i < c->batches.size(); ++i) {
+        const uint32_t *cnt = snap.data() + i * RT_COUNTER_WORDS;
+        if (cnt[CNT_OVERFLOW]) {
+            redo.push_back(c->batches[i]);
+        } else {
+            accumulate(c->stats, cnt);
+            c->stats.batches++;
+        }
+    }
+    const bool was_timing = c->timing;
+    c->timing = false;
+    for (const Batch &b : redo) {
+        const uint32_t h = b.y1 - b.y0;
+        if (h <= 1) {
+            set_err("ray/node queues (%llu entries) overflow on a single row; raise the capacity",
+                    (unsigned long long)c->cap);
+            c->timing = was_timing;
+            return RT_E_OVERFLOW;
+        }
+        c->stats.overflow_retries++;
+        rc = render_range_sync(c, b.y0, b.y1, (h + 1) / 2, false);
+        if (rc) {
+            c->timing = was_timing;
+            return rc;
+        }
+    }
+    c->timing = was_timing;
+    c->batches.clear();
+    finish_stats(c);
+    if (stats)
+        *stats = c->stats;
+    return 0;
+}
+
+int rt_hip_render_stats(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb, float *d_rad,
+                        uint32_t row0, uint32_t nrows, void *stream, rt_hip_stats *stats)
+{
+    int rc = check_args(c, cam, d_argb, row0, nrows);
+    if (rc)
+        return rc;
+    rc = ctx_set_device(c);
+    if (rc)
+        return rc;
+    if (c->pending) {
+        rc = rt_hip_finish(c, nullptr);
+        if (rc)
+            return rc;
+    }
+    c->cam = *cam;
+    fold_camera(c->C, *cam);
+    c->d_argb = d_argb;
+    c->d_rad = d_rad;
+    c->row0 = row0;
+    c->nrows = nrows;
+    c->stream = (hipStream_t)stream;
+    memset(&c->stats, 0, sizeof c->stats);
+    if (nrows) {
+        const uint32_t rows = rows_per_batch(c, default_batch_samples(c));
+        const uint32_t brow = rows < nrows ? rows : nrows;
+        rc = ensure_pix(c, (size_t)brow * c->C.W);
+        if (rc)
+            return rc;
+        rc = render_range_sync(c, row0, row0 + nrows, rows, true);
+        if (rc)
+            return rc;
+    }
+    finish_stats(c);
+    if (stats)
+        *stats = c->stats;
+    return 0;
+}
+
+/* ---- host-pointer entry points ---------------------------------------------------------- */
+
+static std::mutex g_mu;
+static rt_hip_ctx *g_ctx = nullptr; /* cached context of the blocking host path */
+
+int rt_hip_render(const rt_scene *scene, const rt_camera *cam, rt_framebuffer *fb)
+{
+    if (!scene || !cam || !fb || !fb->argb) {
+        set_err("null argument");
+        return RT_E_INVALID;
+    }
+    if (fb->width != cam->frameBufferWidth || fb->height != cam->frameBufferHeight) {
+        set_err("frame buffer %ux%u does not match the camera's %ux%u", fb->width, fb->height,
+                cam->frameBufferWidth, cam->frameBufferHeight);
+        return RT_E_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc;
+    /* queue capacity sized to the job: 2 entries per primary sample, 1 Mi .. default */
+    const uint64_t samples = (uint64_t)fb->width * fb->nrows * cam->sqrtSpp * cam->sqrtSpp;
+    uint64_t want = samples * 2 < (1ull << 20) ? (1ull << 20) : samples * 2;
+    if (want > kDefaultCap)
+        want = kDefaultCap;
+    if (g_ctx && g_ctx->cap < want) {
+        rt_hip_ctx_destroy(g_ctx);
+        g_ctx = nullptr;
+    }
+    if (!g_ctx) {
+        rc = rt_hip_ctx_create(&g_ctx, -1, want);
+        if (rc)
+            return rc;
+    }
+    rc = rt_hip_scene_upload(g_ctx, scene);
+    if (rc)
+        return rc;
+    const size_t npix = (size_t)fb->width * fb->height;
+    uint32_t *d_argb = nullptr;
+    float *d_rad = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_argb, npix * sizeof(uint32_t)));
+    if (fb->radiance) {
+        hipError_t e = hipMalloc((void **)&d_rad, npix * 3 * sizeof(float));
+        if (e != hipSuccess) {
+            (void)hipFree(d_argb);
+            set_err("hipMalloc radiance: %s", hipGetErrorString(e));
+            return -(int)e;
+        }
+    }
+    rc = rt_hip_render_rows(g_ctx, cam, d_argb, d_rad, fb->row0, fb->nrows, nullptr);
+    if (!rc)
+        rc = rt_hip_finish(g_ctx, nullptr);
+    if (!rc && fb->nrows) {
+        const size_t off = (size_t)fb->row0 * fb->width, cnt = (size_t)fb->nrows * fb->width;
+        hipError_t e = hipMemcpy(fb->argb + off, d_argb + off, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && fb->radiance)
+            e = hipMemcpy(fb->radiance + 3 * off, d_rad + 3 * off, cnt * 3 * sizeof(float),
+                          hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            set_err("copying pixels back: %s", hipGetErrorString(e));
+            rc = -(int)e;
+        }
+    }
+    (void)hipFree(d_argb);
+    if (d_rad)
+        (void)hipFree(d_rad);
+    return rc;
+}
+
+void raytrace(unsigned int *buffer, rt_scene_t *scene, float fovY, float aspectRatio, float nearZ,
+              float farZ, unsigned int width, unsigned int height, unsigned int samplesPerPixelSq,
+              unsigned int depth)
+{
+    (void)farZ; /* never read by the reference either */
+    rt_camera cam;
+    rt_camera_prepare(&cam, scene, width, height, samplesPerPixelSq, fovY, aspectRatio, nearZ, depth);
+    /* prepare_scene writes these into the caller's scene (raytrace.c:77-84, 894) */
+    scene->viewDistance = cam.viewDistance;
+    scene->viewPlaneHalfHeight = cam.viewPlaneHalfHeight;
+    scene->viewPlaneHalfWidth = cam.viewPlaneHalfWidth;
+    scene->sppWidth = cam.sppWidth;
+    scene->frameBufferWidth = width;
+    scene->frameBufferHeight = height;
+    scene->sqrtSpp = samplesPerPixelSq;
+
+    rt_scene view;
+    view.bgColor = scene->bgColor;
+    view.ambientLightColor = scene->ambientLightColor;
+    view.nLights = scene->nLights;
+    view.nObjects = scene->nObjects;
+    view.lights = scene->lights;
+    view.objects = scene->objects;
+    rt_framebuffer fb;
+    fb.argb = buffer;
+    fb.radiance = nullptr;
+    fb.width = width;
+    fb.height = height;
+    fb.row0 = 0;
+    fb.nrows = height;
+    const int rc = rt_hip_render(&view, &cam, &fb);
+    if (rc) {
+        fprintf(stderr, "raytrace (HIP): error %d: %s\n", rc, rt_hip_last_error());
+        exit(1);
+    }
+}
+
+} /* extern "C" */

@@ -1,0 +1,93 @@
+/*
+ * rt_device.h - device-side data layout shared by rt_kernels.hip and rt_api.hip.
+ *
+ * Everything the kernels read lives in HBM as SoA / float4 streams (no pointers to host
+ * structs).  See DESIGN.md "Data layout in HBM".
+ */
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RT_MAX_LEVELS   64          /* supported recursion depth: 0 .. RT_MAX_LEVELS-2 */
+#define RT_NONE         0xFFFFFFFFu
+#define RT_LINK_NONE    0x1FFFFFFFu /* 29-bit "no parent / end of chain" */
+#define RT_TILE_SPHERES 2048        /* spheres per LDS tile (32 KiB)  */
+#define RT_MAX_POLY_LDS 1024        /* float4 slots for planes + info + vertices in LDS */
+#define RT_BLOCK        256
+
+/* Camera constants, pre-folded on the host with the reference's float rounding
+ * (raytrace.c:737,751-768): everything that does not depend on the pixel. */
+struct DevCamera {
+    float eye[3];
+    float U[3], V[3];
+    float shiftN[3];     /* N * viewDistance                 raytrace.c:751 */
+    float halfW, halfH;  /* viewPlaneHalfWidth/Height                       */
+    float hfbW, hfbH;    /* frameBufferWidth/2.0f, frameBufferHeight/2.0f   */
+    float sppW, sppHalf; /* sppWidth, sppWidth/2.0f                         */
+    float scale;         /* 1.0f/(float)(sqrtSpp*sqrtSpp)    raytrace.c:737 */
+    uint32_t W, H, sqrtSpp, depth;
+};
+
+/* Flattened scene (all device pointers). */
+struct DevScene {
+    const float4 *sph;        /* [nSph]  (cx, cy, cz, r*r)                           */
+    const uint32_t *sph_obj;  /* [nSph]  object index of sphere k (ascending)        */
+    const float4 *poly;       /* [nPolySlots] planes, then info, then vertex pool:
+                                 poly[p]            = (A,B,C,F)
+                                 poly[nPoly+p]      = bits(vtx offset, nv, obj, 0)
+                                 poly[2*nPoly+v]    = vertex v (x,y,z,w)              */
+    const float4 *objA;       /* [nObj] (diffuse rgb, ka)                            */
+    const float4 *objB;       /* [nObj] (specular rgb, ks)                           */
+    const float4 *objC;       /* [nObj] (kd, ke, kr, kt)                             */
+    const float4 *objD;       /* [nObj] (n, bits type, bits geometry-list index, 0)  */
+    const float4 *objE;       /* [nObj] sphere centre xyz | polygon plane normal ABC */
+    const float4 *light_pos;  /* [nLights] */
+    const float4 *light_col;  /* [nLights] */
+    uint32_t nSph, nPoly, nPolySlots, nObj, nLights;
+    float bg[3];
+    float ambient[3];
+};
+
+/* Per-batch work state in HBM. */
+struct DevWork {
+    float4 *qA[2];        /* ray queues, ping-pong by level parity: (ox,oy,oz,magnitude) */
+    float4 *qB[2];        /*                                         (dx,dy,dz,bits parent<<1|slot) */
+    float4 *nodeA;        /* (local rgb, kr)                                           */
+    float4 *nodeB;        /* (reflection child rgb, kt)                                */
+    float4 *nodeC;        /* (transmission child rgb, bits link)                       */
+    float4 *pixAcc;       /* per pixel of the batch: (immediate sum rgb, bits head)    */
+    uint32_t *counters;   /* DevCounters of this batch                                 */
+    uint32_t cap;         /* entries per queue / node pool                             */
+};
+
+/* Counter block (uint32 words, zeroed per batch by hipMemsetAsync). */
+enum {
+    CNT_QCOUNT = 0,                          /* [RT_MAX_LEVELS] rays queued for level d */
+    CNT_NCOUNT = RT_MAX_LEVELS,              /* [RT_MAX_LEVELS] tree nodes made at level d */
+    CNT_OVERFLOW = 2 * RT_MAX_LEVELS,        /* != 0: a queue or the node pool overflowed */
+    CNT_PAD = 2 * RT_MAX_LEVELS + 1,
+    CNT_STATS64 = 2 * RT_MAX_LEVELS + 2,     /* uint64 statistics start here (8-B aligned) */
+};
+/* uint64 statistic slots (index into (uint64*)(counters + CNT_STATS64)) */
+enum {
+    ST_K0_SHADE_NODES = 0, ST_K0_TRANS, ST_K0_REFL,
+    ST_KB_SHADE_NODES, ST_KB_TRANS, ST_KB_REFL,
+    /* instrumented build only */
+    ST_SPH_TESTS, ST_SPH_HITS, ST_POLY_TESTS, ST_POLY_PAR, ST_POLY_BEHIND, ST_POLY_FULL, ST_POLY_HITS,
+    ST_LIT, ST_NODES_SPH, ST_NODES_POLY,
+    ST_K0_SPH_TESTS, ST_K0_SPH_HITS, ST_K0_POLY_TESTS, ST_K0_POLY_PAR, ST_K0_POLY_BEHIND,
+    ST_K0_POLY_FULL, ST_K0_LIT, ST_K0_NODES_SPH, ST_K0_NODES_POLY,
+    ST_COUNT
+};
+#define RT_COUNTER_WORDS (CNT_STATS64 + 2 * ST_COUNT)
+
+/* launch wrappers implemented in rt_kernels.hip (all asynchronous on `stream`) */
+void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t y0,
+                       uint32_t y1, bool stats, hipStream_t stream);
+void rt_launch_bounce(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t level,
+                      bool stats, hipStream_t stream);
+void rt_launch_fold(const DevWork &Wk, uint32_t level, hipStream_t stream);
+void rt_launch_resolve(const DevCamera &C, const DevWork &Wk, uint32_t y0, uint32_t y1,
+                       uint32_t *d_argb, float *d_radiance, hipStream_t stream);
+size_t rt_scene_lds_bytes(const DevScene &S);

@@ -1,0 +1,791 @@
+/*
+ * rt_kernels.hip - hand-written HIP kernels (gfx950 / CDNA4, wave64) for the Whitted
+ * trace-and-shade loop of davidoguns/raytracer (raytrace.c:160-564, 688-790).
+ *
+ * Pipeline per image batch:
+ *   k_primary  : one lane per pixel, loops the sqrtSpp x sqrtSpp sample grid; primary rays are
+ *                generated and traced in registers (never touch HBM), depth-0 shade nodes are
+ *                lit (shadow rays any-hit inline), childless samples accumulate in registers,
+ *                samples that spawn reflection/transmission rays allocate a tree node and push
+ *                rays to the level-1 queue with wave ballot / prefix-sum compaction.
+ *   k_bounce(d): one lane per queued ray of level d: filtered closest hit, shade, spawn to d+1.
+ *   k_fold(d)  : deepest level first, node colour = clamp(local + kr*refl + kt*trans) written
+ *                into the parent's child slot (the reference clamps at every recursion level,
+ *                raytrace.c:562, so the tree cannot be flattened into a throughput product).
+ *   k_resolve  : per pixel, fold the depth-0 roots, sum, scale by 1/spp^2, pack ARGB8.
+ *
+ * Intersect-all stages the sphere list (cx,cy,cz,r^2) in LDS tiles and every lane of the wave
+ * reads the same entry (same-address broadcast, conflict-free); polygon planes, info words and
+ * vertices are staged once per block.
+ *
+ * Numerics: compiled with -ffp-contract=off; every float op is individually rounded in the
+ * order the reference's C expressions evaluate, sqrt/div are IEEE-correct (hipcc default), and
+ * the reference's double-precision islands (sphere roots ray.c:217-218, refraction
+ * raytrace.c:517-518, angle sum ray.c:98,169) are evaluated in double.  acos is evaluated in
+ * float (acosf) and powf by the device libm - the only places results can differ in the last ulp.
+ */
+#include "rt_device.h"
+
+#include <math.h>
+
+namespace {
+
+struct Ray {
+    float ox, oy, oz;
+    float dx, dy, dz;
+    float mag;
+};
+
+/* per-lane work tally of the instrumented (STATS) build; empty otherwise */
+template <bool STATS> struct Tally;
+template <> struct Tally<false> {
+    __device__ __forceinline__ void sph_test() {}
+    __device__ __forceinline__ void sph_hit() {}
+    __device__ __forceinline__ void poly_test() {}
+    __device__ __forceinline__ void poly_par() {}
+    __device__ __forceinline__ void poly_behind() {}
+    __device__ __forceinline__ void poly_full() {}
+    __device__ __forceinline__ void poly_hit() {}
+    __device__ __forceinline__ void lit() {}
+    __device__ __forceinline__ void node(bool) {}
+};
+template <> struct Tally<true> {
+    uint32_t n_sph_test = 0, n_sph_hit = 0, n_poly_test = 0, n_poly_par = 0, n_poly_behind = 0,
+             n_poly_full = 0, n_poly_hit = 0, n_lit = 0, n_node_sph = 0, n_node_poly = 0;
+    __device__ __forceinline__ void sph_test() { ++n_sph_test; }
+    __device__ __forceinline__ void sph_hit() { ++n_sph_hit; }
+    __device__ __forceinline__ void poly_test() { ++n_poly_test; }
+    __device__ __forceinline__ void poly_par() { ++n_poly_par; }
+    __device__ __forceinline__ void poly_behind() { ++n_poly_behind; }
+    __device__ __forceinline__ void poly_full() { ++n_poly_full; }
+    __device__ __forceinline__ void poly_hit() { ++n_poly_hit; }
+    __device__ __forceinline__ void lit() { ++n_lit; }
+    __device__ __forceinline__ void node(bool sphere) { if (sphere) ++n_node_sph; else ++n_node_poly; }
+};
+
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+
+/* sum a per-lane counter over the wave and add it to a 64-bit global statistic */
+__device__ __forceinline__ void wave_add_stat(uint64_t *stats, int slot, uint32_t v)
+{
+    unsigned long long s = v;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+        s += __shfl_xor(s, off, 64);
+    if (lane_id() == 0 && s != 0)
+        atomicAdd((unsigned long long *)&stats[slot], s);
+}
+
+/* vec4_magnitude vector4.c:219-233: (float)sqrt((double)float_sum) == correctly rounded sqrtf */
+__device__ __forceinline__ float mag3(float x, float y, float z)
+{
+    return sqrtf((x * x + y * y) + z * z);
+}
+
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)
+{
+    return (ax * bx + ay * by) + az * bz; /* vec4_dot vector4.c:141-143, left to right */
+}
+
+/* ray_tinypush ray.c:72-86: origin += normalize(direction) * 0.001f (normalize divides) */
+__device__ __forceinline__ void tinypush(Ray &r)
+{
+    const float m = mag3(r.dx, r.dy, r.dz);
+    r.ox = r.ox + (r.dx / m) * 0.001f;
+    r.oy = r.oy + (r.dy / m) * 0.001f;
+    r.oz = r.oz + (r.dz / m) * 0.001f;
+}
+
+/* Distance returned by ray_intersect_sphere (ray.c:209-240) once det >= 0 is known.
+ * wOne = (float)((-B - sqrt(det)) / 2) with the expression in double.  The reference's second
+ * root never wins: wTwo >= wOne always, so `wTwo > 0 && wTwo < w` is false both when
+ * w = wOne > 0 and when w = 0.  Hence w = wOne if det == 0, else max-like (wOne > 0 ? wOne : 0).
+ * B >= 0 gives wOne <= 0 without needing the square root (w = 0, or -B/2 when det == 0). */
+__device__ __forceinline__ float sphere_distance(float B, float det)
+{
+    if (det == 0.0f)
+        return (float)((double)(-B) * 0.5);
+    if (!(B < 0.0f))
+        return 0.0f;
+    const float wOne = (float)(((double)(-B) - sqrt((double)det)) * 0.5);
+    return wOne > 0.0f ? wOne : 0.0f;
+}
+
+/* ray.c:128-176: sum of the angles pt subtends with consecutive vertices, in double; inside
+ * iff sum + .001 > 2*pi.  (v_i - pt) and its length are shared by the two edges that use them;
+ * the values are identical to the reference's recomputation. */
+__device__ __forceinline__ bool polygon_inside(const float4 *vtx, uint32_t nv, float px, float py,
+                                               float pz)
+{
+    const float4 v0 = vtx[0];
+    const float a0x = v0.x - px, a0y = v0.y - py, a0z = v0.z - pz;
+    const float m0 = mag3(a0x, a0y, a0z);
+    float ax = a0x, ay = a0y, az = a0z, ma = m0;
+    double total = 0.0;
+    for (uint32_t i = 1; i < nv; ++i) {
+        const float4 v = vtx[i];
+        const float bx = v.x - px, by = v.y - py, bz = v.z - pz;
+        const float mb = mag3(bx, by, bz);
+        const float c = dot3(ax, ay, az, bx, by, bz) / (ma * mb);
+        total += (double)acosf(c);
+        ax = bx; ay = by; az = bz; ma = mb;
+    }
+    const float c = dot3(ax, ay, az, a0x, a0y, a0z) / (ma * m0);
+    total += (double)acosf(c);
+    return (total + .001) > (2.0 * 3.14159265358979323846);
+}
+
+/* Cooperative copy of n float4 from HBM to LDS by the whole block. */
+__device__ __forceinline__ void block_copy(float4 *dst, const float4 *src, uint32_t n)
+{
+    for (uint32_t i = threadIdx.x; i < n; i += RT_BLOCK)
+        dst[i] = src[i];
+}
+
+/*
+ * Intersect-all: get_object3d_intersect (raytrace.c:188-222, FILTERED=false) and
+ * get_object3d_intersect_excl (raytrace.c:231-272, FILTERED=true: skips the excluded object,
+ * accepts only 0 < d < ray.magnitude).  Objects are visited as "all spheres, then all
+ * polygons"; the reference's rule (strictly smaller distance replaces, so the lowest object
+ * index wins a tie) is kept by comparing (distance, object index) when a polygon ties.
+ *
+ * ANYHIT (shadow rays): the reference only uses "was anything hit" (raytrace.c:334-340), so the
+ * lane stops at its first accepted hit.  STATS disables that early exit and counts every test
+ * the reference would make.
+ *
+ * TILED: the sphere list does not fit one LDS tile; the tile loop contains block barriers, so
+ * every thread of the block must call this function (inactive lanes pass active=false).
+ */
+template <bool TILED, bool FILTERED, bool ANYHIT, bool STATS>
+__device__ __forceinline__ void intersect_all(const DevScene &S, const float4 *lds_poly,
+                                              float4 *lds_sph, bool active, const Ray &r,
+                                              uint32_t exc_sph, uint32_t exc_poly, float &out_d,
+                                              uint32_t &out_obj, Tally<STATS> &tl)
+{
+    float d = 0.0f;
+    uint32_t best_k = RT_NONE; /* winning sphere-list index */
+    bool found = false;
+
+    for (uint32_t t0 = 0; t0 < S.nSph; t0 += RT_TILE_SPHERES) {
+        const uint32_t cnt = min((uint32_t)RT_TILE_SPHERES, S.nSph - t0);
+        if (TILED) {
+            __syncthreads();
+            block_copy(lds_sph, S.sph + t0, cnt);
+            __syncthreads();
+        }
+        if (active && !(ANYHIT && !STATS && found)) {
+            for (uint32_t j = 0; j < cnt; ++j) {
+                const float4 s = lds_sph[j]; /* same address in all lanes: LDS broadcast */
+                if (FILTERED && (t0 + j) == exc_sph)
+                    continue;
+                tl.sph_test();
+                /* ray.c:185-195 */
+                const float ex = r.ox - s.x, ey = r.oy - s.y, ez = r.oz - s.z;
+                const float B = 2.0f * ((r.dx * ex + r.dy * ey) + r.dz * ez);
+                const float Cq = ((ex * ex + ey * ey) + ez * ez) - s.w;
+                const float det = (B * B) - (4.0f * Cq);
+                if (!(det < 0.0f)) {
+                    tl.sph_hit();
+                    if (FILTERED) {
+                        /* only 0 < w < magnitude can be accepted; w > 0 needs B < 0 */
+                        if (B < 0.0f) {
+                            const float w = sphere_distance(B, det);
+                            if (w < r.mag && w > 0.0f) {
+                                if (!found || w < d) {
+                                    d = w;
+                                    best_k = t0 + j;
+                                    found = true;
+                                    if (ANYHIT && !STATS)
+                                        break;
+                                }
+                            }
+                        }
+                    } else {
+                        const float w = sphere_distance(B, det);
+                        if (!found || w < d) {
+                            d = w;
+                            best_k = t0 + j;
+                            found = true;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    uint32_t best_obj = RT_NONE;
+    if (!ANYHIT && found)
+        best_obj = S.sph_obj[best_k];
+
+    if (active && !(ANYHIT && !STATS && found)) {
+        for (uint32_t p = 0; p < S.nPoly; ++p) {
+            if (FILTERED && p == exc_poly)
+                continue;
+            tl.poly_test();
+            const float4 pl = lds_poly[p];
+            /* ray.c:92-117 */
+            const float num = -1.0f * (dot3(pl.x, pl.y, pl.z, r.ox, r.oy, r.oz) + pl.w);
+            const float den = dot3(pl.x, pl.y, pl.z, r.dx, r.dy, r.dz);
+            if (den == 0.0f) {
+                tl.poly_par();
+                continue;
+            }
+            const float w = num / den;
+            if (w < 0.0f) {
+                tl.poly_behind();
+                continue;
+            }
+            tl.poly_full();
+            const float4 info = lds_poly[S.nPoly + p];
+            const uint32_t pobj = __float_as_uint(info.z);
+            /* would this hit be taken at all?  (skips the angle sum when it cannot matter) */
+            bool wins;
+            if (FILTERED)
+                wins = (w < r.mag && w > 0.0f) && (!found || ANYHIT || w < d || (w == d && pobj < best_obj));
+            else
+                wins = !found || w < d || (w == d && pobj < best_obj);
+            if (!wins && !STATS)
+                continue;
+            const float px = r.ox + r.dx * w, py = r.oy + r.dy * w, pz = r.oz + r.dz * w;
+            const bool inside = polygon_inside(lds_poly + 2 * S.nPoly + __float_as_uint(info.x),
+                                               __float_as_uint(info.y), px, py, pz);
+            if (inside) {
+                tl.poly_hit();
+                if (wins) {
+                    d = w;
+                    best_obj = pobj;
+                    found = true;
+                    if (ANYHIT && !STATS)
+                        break;
+                }
+            }
+        }
+    }
+    out_d = d;
+    out_obj = ANYHIT ? (found ? 0u : RT_NONE) : (found ? best_obj : RT_NONE);
+}
+
+/* Wave-aggregated slot allocation: ballot the requesting lanes, one atomicAdd per wave,
+ * exclusive prefix via popcount of the lower lanes (v_mbcnt).  Returns RT_NONE when the lane
+ * did not ask; sets the overflow flag (and returns RT_NONE) when the pool is exhausted. */
+__device__ __forceinline__ uint32_t wave_alloc(bool want, uint32_t *counter, uint32_t cap,
+                                               uint32_t *overflow)
+{
+    uint32_t idx = RT_NONE;
+    if (want) {
+        const unsigned long long m = __ballot(1);
+        const uint32_t lane = lane_id();
+        const int leader = __ffsll((long long)m) - 1;
+        const uint32_t prefix = __popcll(m & ((1ull << lane) - 1ull));
+        uint32_t base = 0;
+        if ((int)lane == leader)
+            base = atomicAdd(counter, (uint32_t)__popcll(m));
+        base = __shfl(base, leader, 64);
+        idx = base + prefix;
+        if (idx >= cap) {
+            atomicOr(overflow, 1u);
+            idx = RT_NONE;
+        }
+    }
+    return idx;
+}
+
+__device__ __forceinline__ float clamp1(float v) { return v > 1.0f ? 1.0f : v; } /* color.c:44-54 */
+
+struct SpawnCounts {
+    uint32_t shade_nodes = 0, refl = 0, trans = 0;
+};
+
+/*
+ * get_shade_color_phong (raytrace.c:282-564) for one hit, minus the recursion: computes the
+ * local colour (ambient + per-light diffuse/specular with inline any-hit shadow rays), then
+ * either returns a finished leaf colour or allocates a tree node and queues the reflection /
+ * transmission rays for the next level.
+ *
+ * eye          : the ray that found the hit (pushed origin, possibly unnormalised direction)
+ * hit, obj, d  : whether this lane has a hit, which object, at what ray parameter
+ * level        : recursion depth of this node
+ * link         : value stored in the node's link word (parent<<3|slot for level >= 1,
+ *                next-root<<3 for level 0); flags are OR-ed in here
+ * Returns true when the lane produced a tree node (index in node_idx); otherwise `leaf` holds
+ * the clamped colour of a childless node.
+ */
+template <bool TILED, bool STATS>
+__device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCamera &C,
+                                                const DevWork &Wk, const float4 *lds_poly,
+                                                float4 *lds_sph, bool hit, const Ray &eye,
+                                                uint32_t obj, float d, uint32_t level,
+                                                uint32_t link, uint32_t node_base,
+                                                float leaf[3], uint32_t &node_idx,
+                                                SpawnCounts &sc, Tally<STATS> &tl)
+{
+    node_idx = RT_NONE;
+    if (!TILED && !hit)
+        return false;
+
+    float4 mA, mB, mC, mD, gE;
+    if (hit) {
+        mA = S.objA[obj];
+        mB = S.objB[obj];
+        mC = S.objC[obj];
+        mD = S.objD[obj];
+        gE = S.objE[obj];
+        sc.shade_nodes++;
+    } else {
+        mA = mB = mC = mD = gE = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const bool is_sphere = __float_as_uint(mD.y) == 1u; /* GEOMETRY_SPHERE */
+    if (hit)
+        tl.node(is_sphere);
+    const uint32_t glist = __float_as_uint(mD.z);
+    const uint32_t exc_sph = is_sphere ? glist : RT_NONE;
+    const uint32_t exc_poly = is_sphere ? RT_NONE : glist;
+
+    /* intersection point: origin + direction * distance (ray.c:121-122, 236-237) */
+    const float px = eye.ox + eye.dx * d, py = eye.oy + eye.dy * d, pz = eye.oz + eye.dz * d;
+
+    /* get_object_color object3d.c:64-117 */
+    float ocr, ocg, ocb;
+    if (is_sphere) {
+        ocr = mA.x; ocg = mA.y; ocb = mA.z;
+    } else {
+        const float u = (px + 15.0f) / 22.0f;   /* get_2dproject_position object3d.c:30-39 */
+        const float v = (pz + 100.0f) / 100.0f;
+        const int xt = (int)(11.0f * u);
+        const int yt = (int)(50.0f * v);
+        ocr = 1.0f; ocb = 0.0f;
+        ocg = ((xt % 2) == (yt % 2)) ? 0.0f : 1.0f;
+    }
+    /* ambient raytrace.c:303-307 */
+    float outr = (ocr * S.ambient[0]) * mA.w;
+    float outg = (ocg * S.ambient[1]) * mA.w;
+    float outb = (ocb * S.ambient[2]) * mA.w;
+
+    /* normal: geometry.c:37-57 */
+    float Nx, Ny, Nz;
+    if (is_sphere) {
+        const float nx = px - gE.x, ny = py - gE.y, nz = pz - gE.z;
+        const float m = mag3(nx, ny, nz);
+        Nx = nx / m; Ny = ny / m; Nz = nz / m;
+    } else {
+        Nx = gE.x; Ny = gE.y; Nz = gE.z;
+    }
+    /* V = normalize(eye.origin - pt) raytrace.c:318-320 */
+    float Vx = eye.ox - px, Vy = eye.oy - py, Vz = eye.oz - pz;
+    {
+        const float m = mag3(Vx, Vy, Vz);
+        Vx = Vx / m; Vy = Vy / m; Vz = Vz / m;
+    }
+
+    float dfr = 0.f, dfg = 0.f, dfb = 0.f, spr = 0.f, spg = 0.f, spb = 0.f;
+    for (uint32_t l = 0; l < S.nLights; ++l) { /* raytrace.c:327-384 */
+        const float4 lp = S.light_pos[l];
+        const float4 lc = S.light_col[l];
+        /* ray_create(pt, light) ray.c:29-41 */
+        Ray sh;
+        sh.ox = px; sh.oy = py; sh.oz = pz;
+        sh.dx = lp.x - px; sh.dy = lp.y - py; sh.dz = lp.z - pz;
+        sh.mag = mag3(sh.dx, sh.dy, sh.dz);
+        const float inv = 1.0f / sh.mag;
+        sh.dx = sh.dx * inv; sh.dy = sh.dy * inv; sh.dz = sh.dz * inv;
+        tinypush(sh);
+        float sd;
+        uint32_t sobj;
+        intersect_all<TILED, true, true, STATS>(S, lds_poly, lds_sph, hit, sh, exc_sph, exc_poly, sd,
+                                                sobj, tl);
+        if (hit && sobj == RT_NONE) {
+            const float t = dot3(sh.dx, sh.dy, sh.dz, Nx, Ny, Nz);
+            if (!(t <= 0.0f)) {
+                tl.lit();
+                const float t2 = 2.0f * t;
+                const float Rx = Nx * t2 - sh.dx, Ry = Ny * t2 - sh.dy, Rz = Nz * t2 - sh.dz;
+                dfr += lc.x * t; dfg += lc.y * t; dfb += lc.z * t;
+                float s = dot3(Rx, Ry, Rz, Vx, Vy, Vz);
+                if (s < 0.0f)
+                    s = 0.0f;
+                s = powf(s, mC.y);
+                spr += lc.x * s; spg += lc.y * s; spb += lc.z * s;
+            }
+        }
+    }
+    if (!hit)
+        return false;
+
+    /* raytrace.c:390-401 */
+    outr += (mC.x * dfr) * ocr + (mB.w * spr) * mB.x;
+    outg += (mC.x * dfg) * ocg + (mB.w * spg) * mB.y;
+    outb += (mC.x * dfb) * ocb + (mB.w * spb) * mB.z;
+
+    const float kr = mC.z, kt = mC.w;
+    const bool want_r = (kr != 0.0f) && (level != C.depth); /* raytrace.c:405 */
+    const bool want_t = (kt != 0.0f) && (level != C.depth); /* raytrace.c:452 */
+    if (!(want_r || want_t)) {
+        leaf[0] = clamp1(outr); /* raytrace.c:562 */
+        leaf[1] = clamp1(outg);
+        leaf[2] = clamp1(outb);
+        return false;
+    }
+
+    /* tree node + child rays */
+    uint32_t *cnt = Wk.counters;
+    const uint32_t local = wave_alloc(true, &cnt[CNT_NCOUNT + level], Wk.cap - min(node_base, Wk.cap),
+                                      &cnt[CNT_OVERFLOW]);
+    if (local == RT_NONE) { /* overflow: the batch will be re-rendered in smaller pieces */
+        leaf[0] = leaf[1] = leaf[2] = 0.0f;
+        return false;
+    }
+    const uint32_t node = node_base + local;
+    node_idx = node;
+    Wk.nodeA[node] = make_float4(outr, outg, outb, kr);
+    Wk.nodeB[node] = make_float4(0.f, 0.f, 0.f, kt);
+    Wk.nodeC[node] = make_float4(0.f, 0.f, 0.f,
+                                 __uint_as_float(link | (want_r ? 2u : 0u) | (want_t ? 4u : 0u)));
+
+    const uint32_t nq = (level + 1) & 1u;
+    uint32_t *qcount = &cnt[CNT_QCOUNT + level + 1];
+
+    /* reflection ray raytrace.c:408-425 */
+    Ray rr;
+    if (want_r) {
+        const float t2 = 2.0f * dot3(Vx, Vy, Vz, Nx, Ny, Nz);
+        rr.ox = px; rr.oy = py; rr.oz = pz;
+        rr.dx = Nx * t2 - Vx; rr.dy = Ny * t2 - Vy; rr.dz = Nz * t2 - Vz;
+        rr.mag = 9999999.9f;
+        tinypush(rr);
+        sc.refl++;
+    }
+    {
+        const uint32_t slot = wave_alloc(want_r, qcount, Wk.cap, &cnt[CNT_OVERFLOW]);
+        if (slot != RT_NONE) {
+            Wk.qA[nq][slot] = make_float4(rr.ox, rr.oy, rr.oz, rr.mag);
+            Wk.qB[nq][slot] = make_float4(rr.dx, rr.dy, rr.dz, __uint_as_float((node << 1) | 0u));
+        }
+    }
+    /* transmission ray raytrace.c:455-537 */
+    Ray tr;
+    if (want_t) {
+        float nit = 1.0f / mD.x;
+        const float Tx = eye.dx * nit, Ty = eye.dy * nit, Tz = eye.dz * nit;
+        const float cs = dot3(Vx, Vy, Vz, Nx, Ny, Nz);
+        float Fx = Nx, Fy = Ny, Fz = Nz;
+        if (cs < 0.0f) { /* inside the object moving out */
+            nit = 1.0f / nit;
+            Fx = Nx * -1.0f; Fy = Ny * -1.0f; Fz = Nz * -1.0f;
+        }
+        const float det = 1.0f + (nit * nit) * (cs * cs - 1.0f);
+        tr.ox = px; tr.oy = py; tr.oz = pz;
+        if (det < 0.0f) { /* total internal reflection :470-489 */
+            const float t2 = 2.0f * dot3(Vx, Vy, Vz, Fx, Fy, Fz);
+            tr.dx = Fx * t2 - Vx; tr.dy = Fy * t2 - Vy; tr.dz = Fz * t2 - Vz;
+            tr.mag = 999999.0f;
+        } else { /* :517-525: 1/n (not nit) times cos, minus a double sqrt */
+            const float k = (float)((double)((1.0f / mD.x) * cs) - sqrt((double)det));
+            tr.dx = Tx + Fx * k; tr.dy = Ty + Fy * k; tr.dz = Tz + Fz * k;
+            tr.mag = 99999.9f;
+        }
+        tinypush(tr);
+        sc.trans++;
+    }
+    {
+        const uint32_t slot = wave_alloc(want_t, qcount, Wk.cap, &cnt[CNT_OVERFLOW]);
+        if (slot != RT_NONE) {
+            Wk.qA[nq][slot] = make_float4(tr.ox, tr.oy, tr.oz, tr.mag);
+            Wk.qB[nq][slot] = make_float4(tr.dx, tr.dy, tr.dz, __uint_as_float((node << 1) | 1u));
+        }
+    }
+    return true;
+}
+
+template <bool STATS>
+__device__ __forceinline__ void flush_tally(uint64_t *st, Tally<STATS> &tl, bool k0)
+{
+    if constexpr (STATS) {
+        wave_add_stat(st, ST_SPH_TESTS, tl.n_sph_test);
+        wave_add_stat(st, ST_SPH_HITS, tl.n_sph_hit);
+        wave_add_stat(st, ST_POLY_TESTS, tl.n_poly_test);
+        wave_add_stat(st, ST_POLY_PAR, tl.n_poly_par);
+        wave_add_stat(st, ST_POLY_BEHIND, tl.n_poly_behind);
+        wave_add_stat(st, ST_POLY_FULL, tl.n_poly_full);
+        wave_add_stat(st, ST_POLY_HITS, tl.n_poly_hit);
+        wave_add_stat(st, ST_LIT, tl.n_lit);
+        wave_add_stat(st, ST_NODES_SPH, tl.n_node_sph);
+        wave_add_stat(st, ST_NODES_POLY, tl.n_node_poly);
+        if (k0) {
+            wave_add_stat(st, ST_K0_SPH_TESTS, tl.n_sph_test);
+            wave_add_stat(st, ST_K0_SPH_HITS, tl.n_sph_hit);
+            wave_add_stat(st, ST_K0_POLY_TESTS, tl.n_poly_test);
+            wave_add_stat(st, ST_K0_POLY_PAR, tl.n_poly_par);
+            wave_add_stat(st, ST_K0_POLY_BEHIND, tl.n_poly_behind);
+            wave_add_stat(st, ST_K0_POLY_FULL, tl.n_poly_full);
+            wave_add_stat(st, ST_K0_LIT, tl.n_lit);
+            wave_add_stat(st, ST_K0_NODES_SPH, tl.n_node_sph);
+            wave_add_stat(st, ST_K0_NODES_POLY, tl.n_node_poly);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* k_primary: get_pixel_color + get_ray_color + depth-0 get_shade_color_phong, fused           */
+/* ------------------------------------------------------------------------------------------ */
+template <bool TILED, bool STATS>
+__global__ __launch_bounds__(RT_BLOCK) void k_primary(DevScene S, DevCamera C, DevWork Wk,
+                                                      uint32_t y0, uint32_t y1)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 lds[];
+    float4 *lds_poly = lds;
+    float4 *lds_sph = lds + S.nPolySlots;
+    block_copy(lds_poly, S.poly, S.nPolySlots);
+    if (!TILED)
+        block_copy(lds_sph, S.sph, S.nSph);
+    __syncthreads();
+
+    /* a wave owns an 8x8 pixel tile; the block is 4 tiles side by side (32x8 pixels) */
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t x = blockIdx.x * 32u + wv * 8u + (lane & 7u);
+    const uint32_t y = y0 + blockIdx.y * 8u + (lane >> 3);
+    const bool valid = (x < C.W) && (y < y1);
+
+    /* raytrace.c:755-763: the pixel-dependent part of the U and V shifts */
+    const float fu0 = (((float)x - C.hfbW) / C.hfbW) * C.halfW;
+    const float fv0 = ((C.hfbH - (float)y) / C.hfbH) * C.halfH;
+
+    float accr = 0.0f, accg = 0.0f, accb = 0.0f; /* color_init raytrace.c:908 */
+    uint32_t head = RT_LINK_NONE;
+    SpawnCounts sc;
+    Tally<STATS> tl;
+
+    for (uint32_t j = 0; j < C.sqrtSpp; ++j) {
+        const float fv = fv0 + (C.sppHalf + (float)j * C.sppW);
+        for (uint32_t i = 0; i < C.sqrtSpp; ++i) {
+            const float fu = fu0 + (C.sppHalf + (float)i * C.sppW);
+            /* shift = N*vd + U*fu + V*fv; target = eye + shift; ray_create(eye, target) */
+            const float sx = (C.shiftN[0] + C.U[0] * fu) + C.V[0] * fv;
+            const float sy = (C.shiftN[1] + C.U[1] * fu) + C.V[1] * fv;
+            const float sz = (C.shiftN[2] + C.U[2] * fu) + C.V[2] * fv;
+            const float tx = C.eye[0] + sx, ty = C.eye[1] + sy, tz = C.eye[2] + sz;
+            Ray r;
+            r.ox = C.eye[0]; r.oy = C.eye[1]; r.oz = C.eye[2];
+            r.dx = tx - r.ox; r.dy = ty - r.oy; r.dz = tz - r.oz;
+            r.mag = mag3(r.dx, r.dy, r.dz);
+            const float inv = 1.0f / r.mag;
+            r.dx = r.dx * inv; r.dy = r.dy * inv; r.dz = r.dz * inv;
+
+            float d;
+            uint32_t obj;
+            intersect_all<TILED, false, false, STATS>(S, lds_poly, lds_sph, valid, r, RT_NONE, RT_NONE,
+                                                      d, obj, tl);
+            const bool hit = valid && (obj != RT_NONE);
+            float leaf[3] = {S.bg[0], S.bg[1], S.bg[2]}; /* miss: raytrace.c:700-703 */
+            uint32_t node;
+            const bool deferred = shade_and_spawn<TILED, STATS>(S, C, Wk, lds_poly, lds_sph, hit, r, obj, d,
+                                                                0u, head << 3, 0u, leaf, node, sc, tl);
+            if (deferred) {
+                head = node; /* resolved later; chain of this pixel's roots */
+            } else {
+                accr = accr + leaf[0]; /* color_add raytrace.c:774 */
+                accg = accg + leaf[1];
+                accb = accb + leaf[2];
+            }
+        }
+    }
+    if (valid)
+        Wk.pixAcc[(size_t)(y - y0) * C.W + x] = make_float4(accr, accg, accb, __uint_as_float(head));
+
+    uint64_t *st = (uint64_t *)(Wk.counters + CNT_STATS64);
+    wave_add_stat(st, ST_K0_SHADE_NODES, sc.shade_nodes);
+    wave_add_stat(st, ST_K0_REFL, sc.refl);
+    wave_add_stat(st, ST_K0_TRANS, sc.trans);
+    flush_tally<STATS>(st, tl, true);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* k_bounce: one queued secondary ray per lane (reflection / transmission of level-1 nodes)    */
+/* ------------------------------------------------------------------------------------------ */
+template <bool TILED, bool STATS>
+__global__ __launch_bounds__(RT_BLOCK) void k_bounce(DevScene S, DevCamera C, DevWork Wk,
+                                                     uint32_t level)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 lds[];
+    float4 *lds_poly = lds;
+    float4 *lds_sph = lds + S.nPolySlots;
+
+    const uint32_t *cnt = Wk.counters;
+    const uint32_t n = min(cnt[CNT_QCOUNT + level], Wk.cap);
+    if (blockIdx.x * RT_BLOCK >= n)
+        return; /* block-uniform */
+
+    block_copy(lds_poly, S.poly, S.nPolySlots);
+    if (!TILED)
+        block_copy(lds_sph, S.sph, S.nSph);
+    __syncthreads();
+
+    /* first node index of this level = nodes made by all shallower levels */
+    uint32_t node_base = 0;
+    for (uint32_t l = 0; l < level; ++l)
+        node_base += cnt[CNT_NCOUNT + l];
+
+    const uint32_t q = level & 1u;
+    SpawnCounts sc;
+    Tally<STATS> tl;
+    for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        const bool active = i < n;
+        Ray r;
+        uint32_t parent = 0;
+        if (active) {
+            const float4 a = Wk.qA[q][i], b = Wk.qB[q][i];
+            r.ox = a.x; r.oy = a.y; r.oz = a.z; r.mag = a.w;
+            r.dx = b.x; r.dy = b.y; r.dz = b.z;
+            parent = __float_as_uint(b.w);
+        } else {
+            r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.mag = 0.0f;
+        }
+        float d;
+        uint32_t obj;
+        intersect_all<TILED, true, false, STATS>(S, lds_poly, lds_sph, active, r, RT_NONE, RT_NONE, d, obj,
+                                                 tl);
+        const bool hit = active && (obj != RT_NONE);
+        float leaf[3] = {S.bg[0], S.bg[1], S.bg[2]}; /* miss: kr/kt * bgColor raytrace.c:446,509,553 */
+        uint32_t node;
+        const bool deferred = shade_and_spawn<TILED, STATS>(S, C, Wk, lds_poly, lds_sph, hit, r, obj, d, level,
+                                                            ((parent >> 1) << 3) | (parent & 1u), node_base, leaf, node,
+                                                            sc, tl);
+        if (active && !deferred) {
+            /* finished child colour goes straight into the parent's slot */
+            const uint32_t pn = parent >> 1;
+            float *dst = (float *)((parent & 1u) ? &Wk.nodeC[pn] : &Wk.nodeB[pn]);
+            dst[0] = leaf[0]; dst[1] = leaf[1]; dst[2] = leaf[2];
+        }
+    }
+    uint64_t *st = (uint64_t *)(Wk.counters + CNT_STATS64);
+    wave_add_stat(st, ST_KB_SHADE_NODES, sc.shade_nodes);
+    wave_add_stat(st, ST_KB_REFL, sc.refl);
+    wave_add_stat(st, ST_KB_TRANS, sc.trans);
+    flush_tally<STATS>(st, tl, false);
+}
+
+/* colour of a tree node once both children are known: raytrace.c:440-442, 547-549, 562 */
+__device__ __forceinline__ void fold_node(const float4 A, const float4 B, const float4 Cc,
+                                          float out[3])
+{
+    const uint32_t link = __float_as_uint(Cc.w);
+    float r = A.x, g = A.y, b = A.z;
+    if (link & 2u) { r += A.w * B.x; g += A.w * B.y; b += A.w * B.z; }
+    if (link & 4u) { r += B.w * Cc.x; g += B.w * Cc.y; b += B.w * Cc.z; }
+    out[0] = clamp1(r); out[1] = clamp1(g); out[2] = clamp1(b);
+}
+
+/* k_fold: nodes of `level` (>= 1) -> their parent's child slot */
+__global__ __launch_bounds__(RT_BLOCK) void k_fold(DevWork Wk, uint32_t level)
+{
+    const uint32_t *cnt = Wk.counters;
+    uint32_t start = 0;
+    for (uint32_t l = 0; l < level; ++l)
+        start += cnt[CNT_NCOUNT + l];
+    start = min(start, Wk.cap);
+    const uint32_t end = min(start + cnt[CNT_NCOUNT + level], Wk.cap);
+    for (uint32_t i = start + blockIdx.x * RT_BLOCK + threadIdx.x; i < end; i += gridDim.x * RT_BLOCK) {
+        const float4 A = Wk.nodeA[i], B = Wk.nodeB[i], Cc = Wk.nodeC[i];
+        float c[3];
+        fold_node(A, B, Cc, c);
+        const uint32_t link = __float_as_uint(Cc.w);
+        const uint32_t pn = link >> 3;
+        float *dst = (float *)((link & 1u) ? &Wk.nodeC[pn] : &Wk.nodeB[pn]);
+        dst[0] = c[0]; dst[1] = c[1]; dst[2] = c[2];
+    }
+}
+
+/* k_resolve: per pixel - fold this pixel's depth-0 roots, add them to the in-register sum of
+ * the childless samples, scale (raytrace.c:779), store radiance, pack (raytrace.c:783-790). */
+__global__ __launch_bounds__(RT_BLOCK) void k_resolve(DevCamera C, DevWork Wk, uint32_t y0, uint32_t y1,
+                                                      uint32_t *argb, float *radiance)
+{
+    const size_t npix = (size_t)(y1 - y0) * C.W;
+    for (size_t p = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x; p < npix; p += (size_t)gridDim.x * RT_BLOCK) {
+        const float4 acc = Wk.pixAcc[p];
+        float r = acc.x, g = acc.y, b = acc.z;
+        uint32_t root = __float_as_uint(acc.w);
+        while (root != RT_LINK_NONE) {
+            const float4 A = Wk.nodeA[root], B = Wk.nodeB[root], Cc = Wk.nodeC[root];
+            float c[3];
+            fold_node(A, B, Cc, c);
+            r = r + c[0]; g = g + c[1]; b = b + c[2];
+            root = __float_as_uint(Cc.w) >> 3;
+        }
+        r = r * C.scale; g = g * C.scale; b = b * C.scale;
+        const size_t o = (size_t)y0 * C.W + p;
+        if (radiance) {
+            radiance[3 * o + 0] = r; radiance[3 * o + 1] = g; radiance[3 * o + 2] = b;
+        }
+        /* (unsigned char)(255 * c): truncation, low byte of the int conversion */
+        const uint32_t R = (uint32_t)(int)(255.0f * r) & 0xFFu;
+        const uint32_t G = (uint32_t)(int)(255.0f * g) & 0xFFu;
+        const uint32_t Bl = (uint32_t)(int)(255.0f * b) & 0xFFu;
+        argb[o] = 0xFF000000u | (R << 16) | (G << 8) | Bl;
+    }
+}
+
+} // namespace
+
+/* ------------------------------------------------------------------------------------------ */
+/* launch wrappers                                                                            */
+/* ------------------------------------------------------------------------------------------ */
+
+size_t rt_scene_lds_bytes(const DevScene &S)
+{
+    const uint32_t sph = S.nSph < RT_TILE_SPHERES ? S.nSph : RT_TILE_SPHERES;
+    return (size_t)(S.nPolySlots + sph) * sizeof(float4);
+}
+
+void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t y0,
+                       uint32_t y1, bool stats, hipStream_t stream)
+{
+    const dim3 grid((C.W + 31u) / 32u, (y1 - y0 + 7u) / 8u);
+    const size_t lds = rt_scene_lds_bytes(S);
+    const bool tiled = S.nSph > RT_TILE_SPHERES;
+    if (tiled) {
+        if (stats) k_primary<true, true><<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, y0, y1);
+        else       k_primary<true, false><<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, y0, y1);
+    } else {
+        if (stats) k_primary<false, true><<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, y0, y1);
+        else       k_primary<false, false><<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, y0, y1);
+    }
+}
+
+static uint32_t queue_grid(uint32_t cap)
+{
+    const uint32_t need = (cap + RT_BLOCK - 1) / RT_BLOCK;
+    return need < 2048u ? need : 2048u; /* 8 blocks per CU; the rest is grid-strided */
+}
+
+void rt_launch_bounce(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t level,
+                      bool stats, hipStream_t stream)
+{
+    const uint32_t grid = queue_grid(Wk.cap);
+    const size_t lds = rt_scene_lds_bytes(S);
+    const bool tiled = S.nSph > RT_TILE_SPHERES;
+    if (tiled) {
+        if (stats) k_bounce<true, true><<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, level);
+        else       k_bounce<true, false><<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, level);
+    } else {
+        if (stats) k_bounce<false, true><<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, level);
+        else       k_bounce<false, false><<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, level);
+    }
+}
+
+void rt_launch_fold(const DevWork &Wk, uint32_t level, hipStream_t stream)
+{
+    k_fold<<<queue_grid(Wk.cap), RT_BLOCK, 0, stream>>>(Wk, level);
+}
+
+void rt_launch_resolve(const DevCamera &C, const DevWork &Wk, uint32_t y0, uint32_t y1,
+                       uint32_t *d_argb, float *d_radiance, hipStream_t stream)
+{
+    const size_t npix = (size_t)(y1 - y0) * C.W;
+    size_t grid = (npix + RT_BLOCK - 1) / RT_BLOCK;
+    if (grid > 4096)
+        grid = 4096;
+    if (grid == 0)
+        grid = 1;
+    k_resolve<<<(uint32_t)grid, RT_BLOCK, 0, stream>>>(C, Wk, y0, y1, d_argb, d_radiance);
+}
