@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py - throughput of the HIP trace-and-shade path on BASELINE.json's headline workload.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one full render of the frame: every rank renders its row share with the scene and the
+frame buffer resident in HBM, then (N > 1) the frame-buffer slices are collected with one RCCL
+all-gather.  N = 1 renders BASELINE config 2 (builtin Whitted scene, 1920x1080, 4x4 supersampling,
+depth 8).  N > 1 keeps the per-GPU work fixed (weak scaling): the frame grows to N x the pixels at
+16:9 (N = 4 is BASELINE config 3, 3840x2160).
+
+Rank 0 prints ONE JSON line.  `value` = rays (primary + shadow + reflection + transmission, counted
+by the kernels) of all ranks / max-over-ranks time.  `roofline` prices the dominant kernel
+(k_primary) with the algorithmic FLOP constants of SURVEY.md section 8d against the FP32 vector peak;
+`cpu_baseline` times the reference (or the oracle port) on one host core.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import raytracer_amd as rt  # noqa: E402
+
+PEAK_FP32_TFLOPS = 157.3  # MI355X vector FP32 peak, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def frame_for(n_gpus):
+    """Frame size with n_gpus x the pixels of 1920x1080 at 16:9; height a multiple of 8*n_gpus."""
+    if n_gpus == 1:
+        return 1920, 1080
+    if n_gpus == 4:
+        return 3840, 2160  # BASELINE config 3 (2160 = 4 * 540)
+    h = int(round(1080 * math.sqrt(n_gpus) / (8 * n_gpus))) * 8 * n_gpus
+    w = int(round(h * 16 / 9 / 32)) * 32
+    return w, h
+
+
+def algorithmic_flops_k0(st, samples, n_lights, nv=4):
+    """FLOPs the reference would spend on the work k_primary covers."""
+    sph = 20 * st["k0_sphere_tests"] + 15 * st["k0_sphere_hits"]
+    poly_full = 19 + 27 * nv + 1
+    poly = (12 * st["k0_polygon_rej_parallel"] + 13 * st["k0_polygon_rej_behind"]
+            + poly_full * st["k0_polygon_full"])
+    gen = 50 * samples
+    nodes = 51 * st["k0_nodes_sphere"] + 45 * st["k0_nodes_polygon"]
+    lights = 28 * st["k0_shadow_rays"] + 36 * st["k0_lights_lit"]
+    spawn = 33 * st["k0_reflection_rays"] + 45 * st["k0_transmission_rays"]
+    return sph + poly + gen + nodes + lights + spawn
+
+
+def cpu_baseline(W, H, sqrt_spp, depth, budget_rows):
+    """Reference (oracle/_ref, when it travelled) or the oracle port on ONE host core, on a row
+    slab of the same frame.  Returns the JSON object."""
+    from oracle import oracle_py as O
+    sc = rt.Scene.builtin()
+    row0 = (H - budget_rows) // 2
+    if O.have_ref():
+        # the untouched reference renders whole frames only: time a frame with H*budget/H rows is not
+        # possible, so render the full frame at reduced supersampling-invariant size instead
+        t0 = time.perf_counter()
+        _, cnt = O.ref_raytrace(sc.c, W, H, sqrt_spp, depth)
+        dt = time.perf_counter() - t0
+        rays = cnt["ray_create"] + (cnt["ray_tinypush"] - (cnt["ray_create"] - W * H * sqrt_spp * sqrt_spp))
+        return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "reference",
+                "sample": f"full {W}x{H} frame, sqrtSpp {sqrt_spp}, depth {depth}, gcc -O2 build of the "
+                          f"untouched reference, {dt:.2f} s"}
+    cam = O.prepare_camera(sc.c, W, H, sqrt_spp, depth)
+    t0 = time.perf_counter()
+    _, _, cnt = O.render(sc.c, cam, row0, budget_rows, nthreads=1)
+    dt = time.perf_counter() - t0
+    rays = (cnt["primary_rays"] + cnt["shadow_rays"] + cnt["reflection_rays"] + cnt["transmission_rays"])
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+            "sample": f"rows [{row0},{row0 + budget_rows}) of the {W}x{H} frame, sqrtSpp {sqrt_spp}, "
+                      f"depth {depth}, oracle/rt_oracle.c -O2, {dt:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--sqrt-spp", type=int, default=4)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    W, H = frame_for(world)
+    sqrt_spp, depth = args.sqrt_spp, args.depth
+    scene = rt.Scene.builtin()
+    cam = rt.prepare_camera(scene, W, H, sqrt_spp, depth)
+    ctx = rt.Context(device=local_rank)
+    ctx.upload(scene)
+
+    rows = H // world
+    row0 = rank * rows
+    frame = torch.zeros((H, W), dtype=torch.int32, device=dev)  # 0xFFRRGGBB bit patterns
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ctx.render_rows(cam, frame.data_ptr(), 0, row0, rows, stream)
+        if world > 1:
+            # in-place all-gather of the row slabs: rank r owns rows [r*rows, (r+1)*rows)
+            dist.all_gather_into_tensor(frame.view(-1), frame[row0:row0 + rows].reshape(-1))
+
+    # instrumented pass (outside the timed region): algorithmic work of this rank's share
+    st_alg = ctx.render_stats(cam, frame.data_ptr(), 0, row0, rows, stream).as_dict()
+
+    for _ in range(args.warmup):
+        step()
+        ctx.finish()
+    ctx.set_timing(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    k0_ms, k0_n, rays_rank = 0.0, 0, 0
+    for _ in range(args.steps):
+        step()
+        st = ctx.finish()  # waits for this step's render, checks the queues, reads the counters
+        k0_ms += st.k0_ms
+        k0_n += st.k0_launches
+        rays_rank += (st.primary_rays + st.shadow_rays + st.reflection_rays + st.transmission_rays)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ctx.set_timing(False)
+
+    tot = torch.tensor([dt, float(rays_rank)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = tot.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dt_max, rays_all = float(tmax[0]), float(tot[1])
+    else:
+        dt_max, rays_all = dt, float(rays_rank)
+
+    if rank == 0:
+        samples = W * rows * sqrt_spp * sqrt_spp
+        flops_k0 = algorithmic_flops_k0(st_alg, samples, scene.c.nLights)
+        k0_avg_ms = k0_ms / max(k0_n, 1)
+        launches_per_step = k0_n / max(args.steps, 1)
+        achieved = flops_k0 / max(launches_per_step, 1) / (k0_avg_ms * 1e-3) / 1e12 if k0_avg_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/s (primary+secondary) Whitted 1080p 16spp at 1/8 GPUs; % FP32 VALU peak",
+            "value": rays_all / dt_max / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (the reference's hard-coded Whitted scene, scene.c:86-258)",
+            "config": {"workload": f"builtin Whitted scene {W}x{H}, sqrtSpp {sqrt_spp} ({sqrt_spp * sqrt_spp} spp), "
+                                   f"depth {depth}" + ("" if world == 1 else f", {world} row slabs + RCCL all-gather"),
+                       "rays_per_step": rays_all / args.steps,
+                       "parallelism": f"rows/{world}"},
+            "roofline": {"bound": "fp32_valu", "kernel": "k_primary", "achieved": achieved,
+                         "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
+                         "traffic": None, "algorithmic_flop_per_launch": flops_k0 / max(launches_per_step, 1),
+                         "avg_launch_ms": k0_avg_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(W, H, sqrt_spp, depth, budget_rows=H)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
