@@ -34,7 +34,7 @@ void set_err(const char *fmt, ...)
         }                                                                                     \
     } while (0)
 
-constexpr uint32_t kMaxBatches = 1024;          /* counter slots per enqueue round */
+constexpr uint32_t kMaxBatches = 64;            /* counter slots per enqueue round */
 constexpr uint64_t kDefaultCap = 64ull << 20;   /* entries per queue / node pool   */
 
 struct Batch {
@@ -74,6 +74,7 @@ struct rt_hip_ctx {
     bool timing = false;
     uint64_t batch_samples = 0;
     std::vector<hipEvent_t> ev; /* 2 per batch when timing */
+    size_t cwords = RT_COUNTER_WORDS; /* counter words in use per batch (depends on depth) */
     rt_hip_stats stats{};
 };
 
@@ -130,9 +131,9 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
 {
     DevWork Wk = c->W;
     Wk.pixAcc = c->pixAcc;
-    Wk.counters = c->d_counters + (size_t)b.slot * RT_COUNTER_WORDS;
+    Wk.counters = c->d_counters + (size_t)b.slot * c->cwords;
     hipStream_t st = c->stream;
-    HIP_TRY(hipMemsetAsync(Wk.counters, 0, RT_COUNTER_WORDS * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(Wk.counters, 0, c->cwords * sizeof(uint32_t), st));
     const bool timed = c->timing && !stats;
     if (timed) {
         hipEvent_t e0, e1;
@@ -166,12 +167,20 @@ uint32_t rows_per_batch(const rt_hip_ctx *c, uint64_t max_samples)
     return (uint32_t)(rows > 0xFFFFFFFFull ? 0xFFFFFFFFull : rows);
 }
 
-void accumulate(rt_hip_stats &s, const uint32_t *cnt)
+void accumulate(rt_hip_stats &s, const uint32_t *cnt, uint32_t levels)
 {
-    const uint64_t *st = (const uint64_t *)(cnt + CNT_STATS64);
-    for (int l = 0; l < RT_MAX_LEVELS; ++l) {
-        s.queued_rays += cnt[CNT_QCOUNT + l];
-        s.tree_nodes += cnt[CNT_NCOUNT + l];
+    /* (the old single-counter layout is gone: see rt_device.h "Counter block") */
+    for (uint32_t l = 0; l < levels; ++l)
+        for (uint32_t sh = 0; sh < RT_SHARDS; ++sh) {
+            const uint64_t v = *(const uint64_t *)(cnt + CNT_LEVELS + (l * RT_SHARDS + sh) * RT_LINE_WORDS);
+            s.tree_nodes += (uint32_t)v;
+            s.queued_rays += (uint32_t)(v >> 32);
+        }
+    uint64_t st[ST_COUNT] = {0};
+    for (uint32_t sh = 0; sh < RT_SHARDS; ++sh) {
+        const uint64_t *p = (const uint64_t *)(cnt + CNT_STATS + sh * CNT_STATS_STRIDE);
+        for (int k = 0; k < ST_COUNT; ++k)
+            st[k] += p[k];
     }
     s.shade_nodes += st[ST_K0_SHADE_NODES] + st[ST_KB_SHADE_NODES];
     s.reflection_rays += st[ST_K0_REFL] + st[ST_KB_REFL];
@@ -219,12 +228,12 @@ int render_range_sync(rt_hip_ctx *c, uint32_t y0, uint32_t y1, uint32_t rows, bo
             if (rc)
                 return rc;
         }
-        HIP_TRY(hipMemcpyAsync(c->h_counters, c->d_counters, n * RT_COUNTER_WORDS * sizeof(uint32_t),
+        HIP_TRY(hipMemcpyAsync(c->h_counters, c->d_counters, n * c->cwords * sizeof(uint32_t),
                                hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         for (size_t i = 0; i < n; ++i) {
             const Batch &b = todo[done + i];
-            const uint32_t *cnt = c->h_counters + i * RT_COUNTER_WORDS;
+            const uint32_t *cnt = c->h_counters + i * c->cwords;
             if (cnt[CNT_OVERFLOW]) {
                 const uint32_t h = b.y1 - b.y0;
                 if (h <= 1) {
@@ -234,13 +243,13 @@ int render_range_sync(rt_hip_ctx *c, uint32_t y0, uint32_t y1, uint32_t rows, bo
                 }
                 c->stats.overflow_retries++;
                 /* cannot recurse while h_counters of this round is still being read: copy first */
-                std::vector<uint32_t> keep(c->h_counters, c->h_counters + n * RT_COUNTER_WORDS);
+                std::vector<uint32_t> keep(c->h_counters, c->h_counters + n * c->cwords);
                 int rc = render_range_sync(c, b.y0, b.y1, (h + 1) / 2, stats);
                 memcpy(c->h_counters, keep.data(), keep.size() * sizeof(uint32_t));
                 if (rc)
                     return rc;
             } else {
-                accumulate(c->stats, cnt);
+                accumulate(c->stats, cnt, c->C.depth + 1);
                 c->stats.batches++;
             }
         }
@@ -331,6 +340,7 @@ int rt_hip_ctx_create(rt_hip_ctx **out, int device, uint64_t max_queue_rays)
         cap = 1024;
     if (cap > (1ull << 28))
         cap = 1ull << 28; /* node links are 29-bit, ray parents 31-bit */
+    cap = (cap + RT_SHARDS - 1) / RT_SHARDS * RT_SHARDS; /* whole shards */
     c->cap = cap;
     int rc = ctx_set_device(c);
     if (rc) {
@@ -359,6 +369,7 @@ int rt_hip_ctx_create(rt_hip_ctx **out, int device, uint64_t max_queue_rays)
     c->W.nodeB = (float4 *)(p + 5 * arr);
     c->W.nodeC = (float4 *)(p + 6 * arr);
     c->W.cap = (uint32_t)cap;
+    c->W.capS = (uint32_t)(cap / RT_SHARDS);
     *out = c;
     return 0;
 }
@@ -529,6 +540,7 @@ int rt_hip_render_rows(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb, fl
     }
     c->cam = *cam;
     fold_camera(c->C, *cam);
+    c->cwords = RT_COUNTER_WORDS_FOR(cam->depth + 2);
     c->d_argb = d_argb;
     c->d_rad = d_rad;
     c->row0 = row0;
@@ -562,7 +574,7 @@ int rt_hip_render_rows(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb, fl
         y = ye;
     }
     HIP_TRY(hipMemcpyAsync(c->h_counters, c->d_counters,
-                           c->batches.size() * RT_COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                           c->batches.size() * c->cwords * sizeof(uint32_t), hipMemcpyDeviceToHost,
                            c->stream));
     c->pending = true;
     return 0;
@@ -594,13 +606,13 @@ int rt_hip_finish(rt_hip_ctx *c, rt_hip_stats *stats)
     }
     drop_events(c);
     std::vector<Batch> redo;
-    std::vector<uint32_t> snap(c->h_counters, c->h_counters + c->batches.size() * RT_COUNTER_WORDS);
+    std::vector<uint32_t> snap(c->h_counters, c->h_counters + c->batches.size() * c->cwords);
     for (size_t i = 0; i < c->batches.size(); ++i) {
-        const uint32_t *cnt = snap.data() + i * RT_COUNTER_WORDS;
+        const uint32_t *cnt = snap.data() + i * c->cwords;
         if (cnt[CNT_OVERFLOW]) {
             redo.push_back(c->batches[i]);
         } else {
-            accumulate(c->stats, cnt);
+            accumulate(c->stats, cnt, c->C.depth + 1);
             c->stats.batches++;
         }
     }
@@ -645,6 +657,7 @@ int rt_hip_render_stats(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb, f
     }
     c->cam = *cam;
     fold_camera(c->C, *cam);
+    c->cwords = RT_COUNTER_WORDS_FOR(cam->depth + 2);
     c->d_argb = d_argb;
     c->d_rad = d_rad;
     c->row0 = row0;

@@ -57,19 +57,40 @@ struct DevWork {
     float4 *nodeB;        /* (reflection child rgb, kt)                                */
     float4 *nodeC;        /* (transmission child rgb, bits link)                       */
     float4 *pixAcc;       /* per pixel of the batch: (immediate sum rgb, bits head)    */
-    uint32_t *counters;   /* DevCounters of this batch                                 */
+    uint32_t *counters;   /* counter block of this batch (layout below)                */
     uint32_t cap;         /* entries per queue / node pool                             */
+    uint32_t capS;        /* entries per shard = cap / RT_SHARDS                       */
 };
 
-/* Counter block (uint32 words, zeroed per batch by hipMemsetAsync). */
+/*
+ * Counter block (uint32 words, zeroed per batch by hipMemsetAsync).
+ *
+ * Queues and the node pool are split into RT_SHARDS shards, each with its own counters on its
+ * own 128-byte line: one L2 word sustains only ~90 returning atomics per microsecond on MI355X,
+ * and a 1080p frame issues ~10^5 wave-level allocations, so a single tail counter serialises
+ * the whole frame (measured: 1.6 ms -> see DESIGN.md).  A block produces into / consumes from
+ * shard (block index % RT_SHARDS).
+ *
+ *   word 0                      : overflow flag
+ *   CNT_STATS + s*64            : uint64 statistics of shard s (ST_* slots)
+ *   CNT_LEVELS + (L*RT_SHARDS+s)*RT_LINE_WORDS : one uint64 for (level L, shard s):
+ *                                 low 32 bits  = tree nodes made at level L
+ *                                 high 32 bits = rays queued for level L+1
+ *                                 (both are produced by the kernel that processes level L, so a
+ *                                 wave reserves nodes and ray slots with ONE 64-bit atomic)
+ */
+#define RT_SHARDS      64
+#define RT_LINE_WORDS  32
 enum {
-    CNT_QCOUNT = 0,                          /* [RT_MAX_LEVELS] rays queued for level d */
-    CNT_NCOUNT = RT_MAX_LEVELS,              /* [RT_MAX_LEVELS] tree nodes made at level d */
-    CNT_OVERFLOW = 2 * RT_MAX_LEVELS,        /* != 0: a queue or the node pool overflowed */
-    CNT_PAD = 2 * RT_MAX_LEVELS + 1,
-    CNT_STATS64 = 2 * RT_MAX_LEVELS + 2,     /* uint64 statistics start here (8-B aligned) */
+    CNT_OVERFLOW = 0,
+    CNT_STATS = 32,
+    CNT_STATS_STRIDE = 64,
+    CNT_LEVELS = CNT_STATS + RT_SHARDS * CNT_STATS_STRIDE,
 };
-/* uint64 statistic slots (index into (uint64*)(counters + CNT_STATS64)) */
+#define RT_COUNTER_WORDS_FOR(levels) (CNT_LEVELS + (levels) * RT_SHARDS * RT_LINE_WORDS)
+#define RT_COUNTER_WORDS RT_COUNTER_WORDS_FOR(RT_MAX_LEVELS)
+
+/* uint64 statistic slots of a shard */
 enum {
     ST_K0_SHADE_NODES = 0, ST_K0_TRANS, ST_K0_REFL,
     ST_KB_SHADE_NODES, ST_KB_TRANS, ST_KB_REFL,
@@ -80,7 +101,7 @@ enum {
     ST_K0_POLY_FULL, ST_K0_LIT, ST_K0_NODES_SPH, ST_K0_NODES_POLY,
     ST_COUNT
 };
-#define RT_COUNTER_WORDS (CNT_STATS64 + 2 * ST_COUNT)
+static_assert(2 * ST_COUNT <= CNT_STATS_STRIDE, "statistics do not fit their line");
 
 /* launch wrappers implemented in rt_kernels.hip (all asynchronous on `stream`) */
 void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t y0,

@@ -265,29 +265,55 @@ __device__ __forceinline__ void intersect_all(const DevScene &S, const float4 *l
     out_obj = ANYHIT ? (found ? 0u : RT_NONE) : (found ? best_obj : RT_NONE);
 }
 
-/* Wave-aggregated slot allocation: ballot the requesting lanes, one atomicAdd per wave,
- * exclusive prefix via popcount of the lower lanes (v_mbcnt).  Returns RT_NONE when the lane
- * did not ask; sets the overflow flag (and returns RT_NONE) when the pool is exhausted. */
-__device__ __forceinline__ uint32_t wave_alloc(bool want, uint32_t *counter, uint32_t cap,
-                                               uint32_t *overflow)
+/* counter line of (level, shard): low word = nodes made at `level`, high word = rays queued
+ * for level+1 (rt_device.h) */
+__device__ __forceinline__ unsigned long long *level_line(uint32_t *counters, uint32_t level,
+                                                          uint32_t shard)
 {
-    uint32_t idx = RT_NONE;
-    if (want) {
-        const unsigned long long m = __ballot(1);
-        const uint32_t lane = lane_id();
-        const int leader = __ffsll((long long)m) - 1;
-        const uint32_t prefix = __popcll(m & ((1ull << lane) - 1ull));
-        uint32_t base = 0;
-        if ((int)lane == leader)
-            base = atomicAdd(counter, (uint32_t)__popcll(m));
-        base = __shfl(base, leader, 64);
-        idx = base + prefix;
-        if (idx >= cap) {
-            atomicOr(overflow, 1u);
-            idx = RT_NONE;
-        }
+    return (unsigned long long *)(counters + CNT_LEVELS + (level * RT_SHARDS + shard) * RT_LINE_WORDS);
+}
+
+/*
+ * Wave-aggregated reservation of one tree node per calling lane plus ray-queue slots for the
+ * lanes that spawn a reflection and/or a transmission ray: ballot the requests, ONE 64-bit
+ * atomicAdd per wave on the shard's counter line, exclusive prefixes by popcount of the lower
+ * lanes (v_mbcnt).  Must be called by exactly the lanes that want a node.  Reflection rays of
+ * the wave occupy [q, q+nr), transmission rays [q+nr, q+nr+nt).  A reservation past the room
+ * left sets the overflow flag and yields RT_NONE (the host re-renders the batch in smaller pieces).
+ */
+__device__ __forceinline__ void wave_reserve(unsigned long long *line, bool want_r, bool want_t,
+                                             uint32_t node_room, uint32_t ray_room,
+                                             uint32_t *overflow, uint32_t &node_local,
+                                             uint32_t &slot_r, uint32_t &slot_t)
+{
+    const unsigned long long m = __ballot(1);
+    const unsigned long long mr = __ballot(want_r);
+    const unsigned long long mt = __ballot(want_t);
+    const uint32_t lane = lane_id();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int leader = __ffsll((long long)m) - 1;
+    const uint32_t nr = __popcll(mr), nt = __popcll(mt);
+    unsigned long long old = 0;
+    if ((int)lane == leader)
+        old = atomicAdd(line, (unsigned long long)__popcll(m) | ((unsigned long long)(nr + nt) << 32));
+    const uint32_t old_lo = __shfl((uint32_t)old, leader, 64);
+    const uint32_t old_hi = __shfl((uint32_t)(old >> 32), leader, 64);
+    node_local = old_lo + __popcll(m & below);
+    slot_r = old_hi + __popcll(mr & below);
+    slot_t = old_hi + nr + __popcll(mt & below);
+    bool bad = node_local >= node_room;
+    if (bad)
+        node_local = RT_NONE;
+    if (!want_r || bad || slot_r >= ray_room) {
+        bad = bad || (want_r && slot_r >= ray_room);
+        slot_r = RT_NONE;
     }
-    return idx;
+    if (!want_t || node_local == RT_NONE || slot_t >= ray_room) {
+        bad = bad || (want_t && slot_t >= ray_room);
+        slot_t = RT_NONE;
+    }
+    if (bad)
+        atomicOr(overflow, 1u);
 }
 
 __device__ __forceinline__ float clamp1(float v) { return v > 1.0f ? 1.0f : v; } /* color.c:44-54 */
@@ -315,8 +341,8 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
                                                 const DevWork &Wk, const float4 *lds_poly,
                                                 float4 *lds_sph, bool hit, const Ray &eye,
                                                 uint32_t obj, float d, uint32_t level,
-                                                uint32_t link, uint32_t node_base,
-                                                float leaf[3], uint32_t &node_idx,
+                                                uint32_t link, uint32_t shard, uint32_t node_base,
+                                                uint32_t node_room, float leaf[3], uint32_t &node_idx,
                                                 SpawnCounts &sc, Tally<STATS> &tl)
 {
     node_idx = RT_NONE;
@@ -426,10 +452,11 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
         return false;
     }
 
-    /* tree node + child rays */
+    /* tree node + child rays: one reservation per wave */
     uint32_t *cnt = Wk.counters;
-    const uint32_t local = wave_alloc(true, &cnt[CNT_NCOUNT + level], Wk.cap - min(node_base, Wk.cap),
-                                      &cnt[CNT_OVERFLOW]);
+    uint32_t local, slot_r, slot_t;
+    wave_reserve(level_line(cnt, level, shard), want_r, want_t, node_room, Wk.capS, &cnt[CNT_OVERFLOW],
+                 local, slot_r, slot_t);
     if (local == RT_NONE) { /* overflow: the batch will be re-rendered in smaller pieces */
         leaf[0] = leaf[1] = leaf[2] = 0.0f;
         return false;
@@ -442,7 +469,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
                                  __uint_as_float(link | (want_r ? 2u : 0u) | (want_t ? 4u : 0u)));
 
     const uint32_t nq = (level + 1) & 1u;
-    uint32_t *qcount = &cnt[CNT_QCOUNT + level + 1];
+    const uint32_t qbase = shard * Wk.capS;
 
     /* reflection ray raytrace.c:408-425 */
     Ray rr;
@@ -454,12 +481,9 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
         tinypush(rr);
         sc.refl++;
     }
-    {
-        const uint32_t slot = wave_alloc(want_r, qcount, Wk.cap, &cnt[CNT_OVERFLOW]);
-        if (slot != RT_NONE) {
-            Wk.qA[nq][slot] = make_float4(rr.ox, rr.oy, rr.oz, rr.mag);
-            Wk.qB[nq][slot] = make_float4(rr.dx, rr.dy, rr.dz, __uint_as_float((node << 1) | 0u));
-        }
+    if (slot_r != RT_NONE) {
+        Wk.qA[nq][qbase + slot_r] = make_float4(rr.ox, rr.oy, rr.oz, rr.mag);
+        Wk.qB[nq][qbase + slot_r] = make_float4(rr.dx, rr.dy, rr.dz, __uint_as_float((node << 1) | 0u));
     }
     /* transmission ray raytrace.c:455-537 */
     Ray tr;
@@ -486,12 +510,9 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
         tinypush(tr);
         sc.trans++;
     }
-    {
-        const uint32_t slot = wave_alloc(want_t, qcount, Wk.cap, &cnt[CNT_OVERFLOW]);
-        if (slot != RT_NONE) {
-            Wk.qA[nq][slot] = make_float4(tr.ox, tr.oy, tr.oz, tr.mag);
-            Wk.qB[nq][slot] = make_float4(tr.dx, tr.dy, tr.dz, __uint_as_float((node << 1) | 1u));
-        }
+    if (slot_t != RT_NONE) {
+        Wk.qA[nq][qbase + slot_t] = make_float4(tr.ox, tr.oy, tr.oz, tr.mag);
+        Wk.qB[nq][qbase + slot_t] = make_float4(tr.dx, tr.dy, tr.dz, __uint_as_float((node << 1) | 1u));
     }
     return true;
 }
@@ -549,6 +570,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_primary(DevScene S, DevCamera C, D
     const float fu0 = (((float)x - C.hfbW) / C.hfbW) * C.halfW;
     const float fv0 = ((C.hfbH - (float)y) / C.hfbH) * C.halfH;
 
+    const uint32_t shard = (blockIdx.y * gridDim.x + blockIdx.x) % RT_SHARDS;
+    const uint32_t node_base = shard * Wk.capS; /* level 0 opens every shard's node range */
+
     float accr = 0.0f, accg = 0.0f, accb = 0.0f; /* color_init raytrace.c:908 */
     uint32_t head = RT_LINK_NONE;
     SpawnCounts sc;
@@ -578,7 +602,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_primary(DevScene S, DevCamera C, D
             float leaf[3] = {S.bg[0], S.bg[1], S.bg[2]}; /* miss: raytrace.c:700-703 */
             uint32_t node;
             const bool deferred = shade_and_spawn<TILED, STATS>(S, C, Wk, lds_poly, lds_sph, hit, r, obj, d,
-                                                                0u, head << 3, 0u, leaf, node, sc, tl);
+                                                                0u, head << 3, shard, node_base, Wk.capS, leaf,
+                                                                node, sc, tl);
             if (deferred) {
                 head = node; /* resolved later; chain of this pixel's roots */
             } else {
@@ -591,7 +616,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_primary(DevScene S, DevCamera C, D
     if (valid)
         Wk.pixAcc[(size_t)(y - y0) * C.W + x] = make_float4(accr, accg, accb, __uint_as_float(head));
 
-    uint64_t *st = (uint64_t *)(Wk.counters + CNT_STATS64);
+    uint64_t *st = (uint64_t *)(Wk.counters + CNT_STATS + shard * CNT_STATS_STRIDE);
     wave_add_stat(st, ST_K0_SHADE_NODES, sc.shade_nodes);
     wave_add_stat(st, ST_K0_REFL, sc.refl);
     wave_add_stat(st, ST_K0_TRANS, sc.trans);
@@ -609,9 +634,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_bounce(DevScene S, DevCamera C, De
     float4 *lds_poly = lds;
     float4 *lds_sph = lds + S.nPolySlots;
 
-    const uint32_t *cnt = Wk.counters;
-    const uint32_t n = min(cnt[CNT_QCOUNT + level], Wk.cap);
-    if (blockIdx.x * RT_BLOCK >= n)
+    /* block b consumes shard b % RT_SHARDS, as slice b / RT_SHARDS of gridDim.x / RT_SHARDS */
+    const uint32_t shard = blockIdx.x % RT_SHARDS;
+    const uint32_t slice = blockIdx.x / RT_SHARDS, nslices = gridDim.x / RT_SHARDS;
+    uint32_t *cnt = Wk.counters;
+    const uint32_t n = min((uint32_t)(*level_line(cnt, level - 1, shard) >> 32), Wk.capS);
+    if (slice * RT_BLOCK >= n)
         return; /* block-uniform */
 
     block_copy(lds_poly, S.poly, S.nPolySlots);
@@ -619,21 +647,25 @@ __global__ __launch_bounds__(RT_BLOCK) void k_bounce(DevScene S, DevCamera C, De
         block_copy(lds_sph, S.sph, S.nSph);
     __syncthreads();
 
-    /* first node index of this level = nodes made by all shallower levels */
-    uint32_t node_base = 0;
+    /* first node index of this level in this shard = nodes made by all shallower levels */
+    uint32_t used = 0;
     for (uint32_t l = 0; l < level; ++l)
-        node_base += cnt[CNT_NCOUNT + l];
+        used += (uint32_t)*level_line(cnt, l, shard);
+    used = min(used, Wk.capS);
+    const uint32_t node_base = shard * Wk.capS + used;
+    const uint32_t node_room = Wk.capS - used;
+    const uint32_t qbase = shard * Wk.capS;
 
     const uint32_t q = level & 1u;
     SpawnCounts sc;
     Tally<STATS> tl;
-    for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
+    for (uint32_t base = slice * RT_BLOCK; base < n; base += nslices * RT_BLOCK) {
         const uint32_t i = base + threadIdx.x;
         const bool active = i < n;
         Ray r;
         uint32_t parent = 0;
         if (active) {
-            const float4 a = Wk.qA[q][i], b = Wk.qB[q][i];
+            const float4 a = Wk.qA[q][qbase + i], b = Wk.qB[q][qbase + i];
             r.ox = a.x; r.oy = a.y; r.oz = a.z; r.mag = a.w;
             r.dx = b.x; r.dy = b.y; r.dz = b.z;
             parent = __float_as_uint(b.w);
@@ -648,8 +680,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_bounce(DevScene S, DevCamera C, De
         float leaf[3] = {S.bg[0], S.bg[1], S.bg[2]}; /* miss: kr/kt * bgColor raytrace.c:446,509,553 */
         uint32_t node;
         const bool deferred = shade_and_spawn<TILED, STATS>(S, C, Wk, lds_poly, lds_sph, hit, r, obj, d, level,
-                                                            ((parent >> 1) << 3) | (parent & 1u), node_base, leaf, node,
-                                                            sc, tl);
+                                                            ((parent >> 1) << 3) | (parent & 1u), shard, node_base,
+                                                            node_room, leaf, node, sc, tl);
         if (active && !deferred) {
             /* finished child colour goes straight into the parent's slot */
             const uint32_t pn = parent >> 1;
@@ -657,7 +689,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_bounce(DevScene S, DevCamera C, De
             dst[0] = leaf[0]; dst[1] = leaf[1]; dst[2] = leaf[2];
         }
     }
-    uint64_t *st = (uint64_t *)(Wk.counters + CNT_STATS64);
+    uint64_t *st = (uint64_t *)(Wk.counters + CNT_STATS + shard * CNT_STATS_STRIDE);
     wave_add_stat(st, ST_KB_SHADE_NODES, sc.shade_nodes);
     wave_add_stat(st, ST_KB_REFL, sc.refl);
     wave_add_stat(st, ST_KB_TRANS, sc.trans);
@@ -678,13 +710,16 @@ __device__ __forceinline__ void fold_node(const float4 A, const float4 B, const 
 /* k_fold: nodes of `level` (>= 1) -> their parent's child slot */
 __global__ __launch_bounds__(RT_BLOCK) void k_fold(DevWork Wk, uint32_t level)
 {
-    const uint32_t *cnt = Wk.counters;
-    uint32_t start = 0;
+    uint32_t *cnt = Wk.counters;
+    const uint32_t shard = blockIdx.x % RT_SHARDS;
+    const uint32_t slice = blockIdx.x / RT_SHARDS, nslices = gridDim.x / RT_SHARDS;
+    uint32_t used = 0;
     for (uint32_t l = 0; l < level; ++l)
-        start += cnt[CNT_NCOUNT + l];
-    start = min(start, Wk.cap);
-    const uint32_t end = min(start + cnt[CNT_NCOUNT + level], Wk.cap);
-    for (uint32_t i = start + blockIdx.x * RT_BLOCK + threadIdx.x; i < end; i += gridDim.x * RT_BLOCK) {
+        used += (uint32_t)*level_line(cnt, l, shard);
+    used = min(used, Wk.capS);
+    const uint32_t start = shard * Wk.capS + used;
+    const uint32_t end = start + min((uint32_t)*level_line(cnt, level, shard), Wk.capS - used);
+    for (uint32_t i = start + slice * RT_BLOCK + threadIdx.x; i < end; i += nslices * RT_BLOCK) {
         const float4 A = Wk.nodeA[i], B = Wk.nodeB[i], Cc = Wk.nodeC[i];
         float c[3];
         fold_node(A, B, Cc, c);
@@ -752,16 +787,21 @@ void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk,
     }
 }
 
-static uint32_t queue_grid(uint32_t cap)
+static uint32_t queue_grid(const DevWork &Wk)
 {
-    const uint32_t need = (cap + RT_BLOCK - 1) / RT_BLOCK;
-    return need < 2048u ? need : 2048u; /* 8 blocks per CU; the rest is grid-strided */
+    /* RT_SHARDS shards x slices; 2048 blocks = 8 per CU, the rest is grid-strided */
+    uint32_t slices = (Wk.capS + RT_BLOCK - 1) / RT_BLOCK;
+    if (slices > 2048u / RT_SHARDS)
+        slices = 2048u / RT_SHARDS;
+    if (slices < 1)
+        slices = 1;
+    return slices * RT_SHARDS;
 }
 
 void rt_launch_bounce(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t level,
                       bool stats, hipStream_t stream)
 {
-    const uint32_t grid = queue_grid(Wk.cap);
+    const uint32_t grid = queue_grid(Wk);
     const size_t lds = rt_scene_lds_bytes(S);
     const bool tiled = S.nSph > RT_TILE_SPHERES;
     if (tiled) {
@@ -775,7 +815,7 @@ void rt_launch_bounce(const DevScene &S, const DevCamera &C, const DevWork &Wk, 
 
 void rt_launch_fold(const DevWork &Wk, uint32_t level, hipStream_t stream)
 {
-    k_fold<<<queue_grid(Wk.cap), RT_BLOCK, 0, stream>>>(Wk, level);
+    k_fold<<<queue_grid(Wk), RT_BLOCK, 0, stream>>>(Wk, level);
 }
 
 void rt_launch_resolve(const DevCamera &C, const DevWork &Wk, uint32_t y0, uint32_t y1,

@@ -1,0 +1,19 @@
+#!/bin/bash
+# usage: tools/pmc.sh <tag> <counters...>   (run on the GPU box from the repo root)
+tag=$1; shift
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_$tag -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_$tag.log 2>&1 || exit 1
+python3 - <<PY
+import csv,glob,collections
+f=glob.glob("gpurun_out/pmc_$tag/**/*counter_collection.csv",recursive=True)[0]
+agg=collections.defaultdict(lambda: collections.defaultdict(float)); calls=collections.Counter()
+seen=set()
+for r in csv.DictReader(open(f)):
+    k=r["Kernel_Name"]
+    if "k_" not in k: continue
+    k=k.split("(")[0][-40:]
+    agg[k][r["Counter_Name"]]+=float(r["Counter_Value"])
+    seen.add((k,r["Dispatch_Id"]))
+for k,d in seen: calls[k]+=1
+for k,v in agg.items(): print(k, "calls",calls[k], {a:"%.4g"%(b/calls[k]) for a,b in v.items()})
+PY
