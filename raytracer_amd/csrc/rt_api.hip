@@ -167,6 +167,14 @@ uint32_t rows_per_batch(const rt_hip_ctx *c, uint64_t max_samples)
     return (uint32_t)(rows > 0xFFFFFFFFull ? 0xFFFFFFFFull : rows);
 }
 
+bool batch_overflowed(const uint32_t *cnt)
+{
+    for (int l = 0; l < RT_MAX_LEVELS; ++l)
+        if (cnt[CNT_OVERFLOW + l])
+            return true;
+    return false;
+}
+
 void accumulate(rt_hip_stats &s, const uint32_t *cnt, uint32_t levels)
 {
     /* (the old single-counter layout is gone: see rt_device.h "Counter block") */
@@ -234,7 +242,7 @@ int render_range_sync(rt_hip_ctx *c, uint32_t y0, uint32_t y1, uint32_t rows, bo
         for (size_t i = 0; i < n; ++i) {
             const Batch &b = todo[done + i];
             const uint32_t *cnt = c->h_counters + i * c->cwords;
-            if (cnt[CNT_OVERFLOW]) {
+            if (batch_overflowed(cnt)) {
                 const uint32_t h = b.y1 - b.y0;
                 if (h <= 1) {
                     set_err("ray/node queues (%llu entries) overflow on a single row; raise the capacity",
@@ -609,7 +617,7 @@ int rt_hip_finish(rt_hip_ctx *c, rt_hip_stats *stats)
     std::vector<uint32_t> snap(c->h_counters, c->h_counters + c->batches.size() * c->cwords);
     for (size_t i = 0; i < c->batches.size(); ++i) {
         const uint32_t *cnt = snap.data() + i * c->cwords;
-        if (cnt[CNT_OVERFLOW]) {
+        if (batch_overflowed(cnt)) {
             redo.push_back(c->batches[i]);
         } else {
             accumulate(c->stats, cnt, c->C.depth + 1);

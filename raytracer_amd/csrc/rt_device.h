@@ -71,7 +71,10 @@ struct DevWork {
  * the whole frame (measured: 1.6 ms -> see DESIGN.md).  A block produces into / consumes from
  * shard (block index % RT_SHARDS).
  *
- *   word 0                      : overflow flag
+ *   word L (L < RT_MAX_LEVELS)  : overflow flag raised by the kernel that processes level L;
+ *                                 every later kernel of the batch returns at once when one is
+ *                                 set (slots reserved by an overflowing wave stay unwritten, so
+ *                                 nothing downstream may consume the queues)
  *   CNT_STATS + s*64            : uint64 statistics of shard s (ST_* slots)
  *   CNT_LEVELS + (L*RT_SHARDS+s)*RT_LINE_WORDS : one uint64 for (level L, shard s):
  *                                 low 32 bits  = tree nodes made at level L
@@ -82,8 +85,8 @@ struct DevWork {
 #define RT_SHARDS      64
 #define RT_LINE_WORDS  32
 enum {
-    CNT_OVERFLOW = 0,
-    CNT_STATS = 32,
+    CNT_OVERFLOW = 0,              /* [RT_MAX_LEVELS] */
+    CNT_STATS = RT_MAX_LEVELS,
     CNT_STATS_STRIDE = 64,
     CNT_LEVELS = CNT_STATS + RT_SHARDS * CNT_STATS_STRIDE,
 };

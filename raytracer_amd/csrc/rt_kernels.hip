@@ -273,6 +273,16 @@ __device__ __forceinline__ unsigned long long *level_line(uint32_t *counters, ui
     return (unsigned long long *)(counters + CNT_LEVELS + (level * RT_SHARDS + shard) * RT_LINE_WORDS);
 }
 
+/* did any kernel that processed a level < `levels` of this batch overflow?  Those kernels have
+ * finished, so the answer is the same for every thread of the launch (block-uniform). */
+__device__ __forceinline__ bool overflowed_before(const uint32_t *counters, uint32_t levels)
+{
+    uint32_t f = 0;
+    for (uint32_t l = 0; l < levels; ++l)
+        f |= counters[CNT_OVERFLOW + l];
+    return f != 0;
+}
+
 /*
  * Wave-aggregated reservation of one tree node per calling lane plus ray-queue slots for the
  * lanes that spawn a reflection and/or a transmission ray: ballot the requests, ONE 64-bit
@@ -455,7 +465,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     /* tree node + child rays: one reservation per wave */
     uint32_t *cnt = Wk.counters;
     uint32_t local, slot_r, slot_t;
-    wave_reserve(level_line(cnt, level, shard), want_r, want_t, node_room, Wk.capS, &cnt[CNT_OVERFLOW],
+    wave_reserve(level_line(cnt, level, shard), want_r, want_t, node_room, Wk.capS, &cnt[CNT_OVERFLOW + level],
                  local, slot_r, slot_t);
     if (local == RT_NONE) { /* overflow: the batch will be re-rendered in smaller pieces */
         leaf[0] = leaf[1] = leaf[2] = 0.0f;
@@ -638,6 +648,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_bounce(DevScene S, DevCamera C, De
     const uint32_t shard = blockIdx.x % RT_SHARDS;
     const uint32_t slice = blockIdx.x / RT_SHARDS, nslices = gridDim.x / RT_SHARDS;
     uint32_t *cnt = Wk.counters;
+    if (overflowed_before(cnt, level))
+        return; /* the batch is being abandoned: its queues hold unwritten slots */
     const uint32_t n = min((uint32_t)(*level_line(cnt, level - 1, shard) >> 32), Wk.capS);
     if (slice * RT_BLOCK >= n)
         return; /* block-uniform */
@@ -682,7 +694,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_bounce(DevScene S, DevCamera C, De
         const bool deferred = shade_and_spawn<TILED, STATS>(S, C, Wk, lds_poly, lds_sph, hit, r, obj, d, level,
                                                             ((parent >> 1) << 3) | (parent & 1u), shard, node_base,
                                                             node_room, leaf, node, sc, tl);
-        if (active && !deferred) {
+        if (active && !deferred && (parent >> 1) < Wk.cap) {
             /* finished child colour goes straight into the parent's slot */
             const uint32_t pn = parent >> 1;
             float *dst = (float *)((parent & 1u) ? &Wk.nodeC[pn] : &Wk.nodeB[pn]);
@@ -711,6 +723,8 @@ __device__ __forceinline__ void fold_node(const float4 A, const float4 B, const 
 __global__ __launch_bounds__(RT_BLOCK) void k_fold(DevWork Wk, uint32_t level)
 {
     uint32_t *cnt = Wk.counters;
+    if (overflowed_before(cnt, RT_MAX_LEVELS))
+        return;
     const uint32_t shard = blockIdx.x % RT_SHARDS;
     const uint32_t slice = blockIdx.x / RT_SHARDS, nslices = gridDim.x / RT_SHARDS;
     uint32_t used = 0;
@@ -725,6 +739,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_fold(DevWork Wk, uint32_t level)
         fold_node(A, B, Cc, c);
         const uint32_t link = __float_as_uint(Cc.w);
         const uint32_t pn = link >> 3;
+        if (pn >= Wk.cap)
+            continue;
         float *dst = (float *)((link & 1u) ? &Wk.nodeC[pn] : &Wk.nodeB[pn]);
         dst[0] = c[0]; dst[1] = c[1]; dst[2] = c[2];
     }
@@ -735,12 +751,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_fold(DevWork Wk, uint32_t level)
 __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DevCamera C, DevWork Wk, uint32_t y0, uint32_t y1,
                                                       uint32_t *argb, float *radiance)
 {
+    if (overflowed_before(Wk.counters, RT_MAX_LEVELS))
+        return; /* rows of an abandoned batch are rendered again by the host in smaller batches */
     const size_t npix = (size_t)(y1 - y0) * C.W;
     for (size_t p = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x; p < npix; p += (size_t)gridDim.x * RT_BLOCK) {
         const float4 acc = Wk.pixAcc[p];
         float r = acc.x, g = acc.y, b = acc.z;
         uint32_t root = __float_as_uint(acc.w);
-        while (root != RT_LINK_NONE) {
+        while (root < Wk.cap) { /* RT_LINK_NONE ends the chain */
             const float4 A = Wk.nodeA[root], B = Wk.nodeB[root], Cc = Wk.nodeC[root];
             float c[3];
             fold_node(A, B, Cc, c);

@@ -1,0 +1,188 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/rt_hip.h declares,
+struct layouts match the reference's, and the host helpers (scene construction, camera, P6 writer)
+reproduce the reference's values.  No compute calls: there is no GPU here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+from raytracer_amd import _abi as A
+from raytracer_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "rt_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z_0-9]+|raytrace)\s*\(", src)) - {"rt_hip_ctx"})
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = _lib.load()
+    names = declared_functions()
+    assert "raytrace" in names and "rt_hip_render" in names
+    for n in names:
+        assert hasattr(lib, n), f"librt_hip.so does not export {n}"
+    assert sorted(_lib.EXPORTS) == names
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(l.split()[-1] for l in out.splitlines() if " T " in l)
+    assert set(names) <= exported
+
+
+def test_layouts_match_reference_x86_64():
+    # SURVEY.md appendix B.1 (measured with sizeof/offsetof on the compiled reference)
+    assert C.sizeof(A.rt_vec4) == 16 and C.sizeof(A.rt_color) == 12 and C.sizeof(A.rt_plane) == 16
+    assert C.sizeof(A.rt_sphere) == 20 and C.sizeof(A.rt_material) == 52
+    assert C.sizeof(A.rt_polygon) == 32 and A.rt_polygon.nVerticies.offset == 16 and A.rt_polygon.vertex.offset == 24
+    assert C.sizeof(A.rt_pointlight) == 32 and A.rt_pointlight.color.offset == 16 and A.rt_pointlight.range.offset == 28
+    assert C.sizeof(A.rt_object3d) == 104 and A.rt_object3d.debugName.offset == 8
+    assert A.rt_object3d.material.offset == 16 and A.rt_object3d.g.offset == 72
+    assert C.sizeof(A.rt_scene_t) == 184
+    for name, off in [("eyePos", 0), ("lookAt", 16), ("upVec", 32), ("U", 48), ("V", 64), ("N", 80),
+                      ("frameBufferWidth", 96), ("frameBufferHeight", 100), ("sqrtSpp", 104), ("viewDistance", 108),
+                      ("viewPlaneHalfWidth", 112), ("viewPlaneHalfHeight", 116), ("sppWidth", 120),
+                      ("bgColor", 124), ("ambientLightColor", 136), ("ldMax", 148), ("lMax", 152),
+                      ("nLights", 156), ("nObjects", 160), ("lights", 168), ("objects", 176)]:
+        assert getattr(A.rt_scene_t, name).offset == off, name
+
+
+def test_header_compiles_as_c_and_cpp(tmp_path):
+    src = '#include "rt_hip.h"\nint main(void){return (int)sizeof(rt_hip_stats) == 256 ? 0 : 1;}\n'
+    for comp, ext in (("gcc", "c"), ("g++", "cpp")):
+        f = tmp_path / f"t.{ext}"
+        f.write_text(src)
+        exe = tmp_path / f"t_{ext}"
+        subprocess.check_call([comp, "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(f), "-o", str(exe)])
+        assert subprocess.call([str(exe)]) == 0
+    assert C.sizeof(A.rt_hip_stats) == 256
+
+
+def test_builtin_scene_equals_the_reference_parse_scene(golden):
+    meta, _ = golden
+    want = meta["builtin_scene"]
+    keep = rt.Scene.builtin()
+    s = keep.c
+    f32 = lambda v: np.array(v, dtype=np.float32)
+    assert s.nObjects == want["nObjects"] and s.nLights == want["nLights"]
+    assert np.array_equal(f32([s.bgColor.r, s.bgColor.g, s.bgColor.b]), f32(want["bg"]))
+    assert np.array_equal(f32([s.ambientLightColor.r, s.ambientLightColor.g, s.ambientLightColor.b]), f32(want["ambient"]))
+    for name in ("eye", "U", "V", "N"):
+        v = getattr(s, "eyePos" if name == "eye" else name)
+        assert np.array_equal(f32([v.x, v.y, v.z]).view(np.uint32), f32(want[name]).view(np.uint32)), name
+    assert np.array_equal(f32([s.lookAt.x, s.lookAt.y, s.lookAt.z, s.lookAt.w]), f32(want["lookAt"]))
+    L = s.lights[0]
+    assert np.array_equal(f32([L.position.x, L.position.y, L.position.z, L.color.r, L.color.g, L.color.b, L.range]),
+                          f32(want["light0"]))
+    for i, od in enumerate(want["objects"]):
+        o = s.objects[i]
+        m = o.material
+        assert o.geometryType == od["type"]
+        got = [m.colors[0].r, m.colors[0].g, m.colors[0].b, m.colors[1].r, m.colors[1].g, m.colors[1].b,
+               m.phong_ka, m.phong_kd, m.phong_ks, m.phong_ke, m.kr, m.kt, m.n]
+        assert np.array_equal(f32(got), f32(od["material"]))
+        if "sphere" in od:
+            c = o.sphr_obj.center
+            assert np.array_equal(f32([c.x, c.y, c.z, o.sphr_obj.radius]), f32(od["sphere"]))
+        else:
+            p = o.poly_obj
+            assert np.array_equal(f32([p.plane.A, p.plane.B, p.plane.C, p.plane.F]).view(np.uint32),
+                                  f32(od["plane"]).view(np.uint32))  # bit-exact incl. the -0.0 in C
+            assert p.nVerticies == len(od["vertices"])
+            for v, wv in enumerate(od["vertices"]):
+                assert np.array_equal(f32([p.vertex[v].x, p.vertex[v].y, p.vertex[v].z, p.vertex[v].w]), f32(wv))
+
+
+def test_camera_prepare_matches_prepare_scene(golden):
+    meta, _ = golden
+    sc = rt.Scene.builtin()
+    for W, H, s, vd, hw, hh, sw in meta["prepare_scene"]:
+        cam = rt.prepare_camera(sc, W, H, s, 4)
+        got = np.array([cam.viewDistance, cam.viewPlaneHalfWidth, cam.viewPlaneHalfHeight, cam.sppWidth], np.float32)
+        assert np.array_equal(got, np.array([vd, hw, hh, sw], np.float32))
+        assert (cam.frameBufferWidth, cam.frameBufferHeight, cam.sqrtSpp, cam.depth) == (W, H, s, 4)
+
+
+def test_poly_plane_kats_and_inward_walls(golden, make_scene):
+    meta, _ = golden
+    lib = _lib.load()
+    for k in meta["kats"]["poly_plane"]:
+        verts = (A.rt_vec4 * 4)(*[A.rt_vec4(v[0], v[1], v[2], 1.0) for v in k["vertices"]])
+        poly = A.rt_polygon()
+        poly.nVerticies = 4
+        poly.vertex = C.cast(verts, C.POINTER(A.rt_vec4))
+        pl = A.rt_plane()
+        lib.rt_poly_plane(C.byref(pl), C.byref(poly))
+        assert np.array_equal(np.array([pl.A, pl.B, pl.C, pl.F], np.float32).view(np.uint32),
+                              np.array(k["plane"], np.float32).view(np.uint32))
+    # the synthetic room's walls must face inwards with n.v0 <= 0 (geometry.c:29-32 forces F = |n.v0|)
+    keep = make_scene("c4")
+    sc = keep.c
+    want = {1024: (0, 1, 0), 1025: (0, 0, 1), 1026: (1, 0, 0), 1027: (-1, 0, 0)}
+    for i, n in want.items():
+        p = sc.objects[i].poly_obj
+        assert sc.objects[i].geometryType == A.RT_GEOMETRY_POLYGON
+        assert (p.plane.A, p.plane.B, p.plane.C) == n
+        v0 = p.vertex[0]
+        assert p.plane.A * v0.x + p.plane.B * v0.y + p.plane.C * v0.z + p.plane.F == 0
+
+
+def test_synthetic_scene_is_deterministic_and_in_spec():
+    keep = [rt.Scene.synthetic(0xC0FFEE04, 1024, 4, 1, 0), rt.Scene.synthetic(0xC0FFEE04, 1024, 4, 1, 0),
+            rt.Scene.synthetic(0xC0FFEE05, 1024, 4, 1, 0)]
+    a, b, c = (k.c for k in keep)
+    same = diff = 0
+    for i in range(1024):
+        sa, sb, sc_ = a.objects[i].sphr_obj, b.objects[i].sphr_obj, c.objects[i].sphr_obj
+        assert (sa.center.x, sa.center.y, sa.center.z, sa.radius) == (sb.center.x, sb.center.y, sb.center.z, sb.radius)
+        diff += (sa.center.x != sc_.center.x)
+        assert -12 <= sa.center.x <= 12 and 0.3 <= sa.center.y <= 8 and -40 <= sa.center.z <= -4
+        assert 0.15 <= sa.radius <= 0.6
+        m = a.objects[i].material
+        assert (m.kr, m.kt) == [(0, 0), (0.75, 0), (np.float32(0.01), np.float32(0.85)),
+                                (np.float32(0.3), np.float32(0.4))][i % 4]
+    assert diff > 1000
+    with pytest.raises(ValueError):
+        rt.Scene.synthetic(1, 0, 0, 1, 0)
+    with pytest.raises(ValueError):
+        rt.Scene.synthetic(1, 10, 5, 1, 0)
+
+
+def test_write_image_is_raw_p6(tmp_path):
+    W, H = 5, 3
+    buf = (0xFF000000 | (np.arange(W * H, dtype=np.uint32) * 0x010203)).astype(np.uint32)
+    f = tmp_path / "o.ppm"
+    assert rt.write_image(f, buf, W, H) == 1
+    data = f.read_bytes()
+    head = b"P6\n5 3\n255\n"
+    assert data.startswith(head) and len(data) == len(head) + 3 * W * H
+    rgb = np.frombuffer(data[len(head):], np.uint8).reshape(-1, 3)
+    assert np.array_equal(rgb[:, 0], (buf >> 16) & 255) and np.array_equal(rgb[:, 2], buf & 255)
+    assert rt.write_image(tmp_path / "nodir" / "o.ppm", buf, W, H) == 0
+
+
+def test_parse_scene_ignores_contents_and_reports_missing_file(tmp_path):
+    f = tmp_path / "scene"
+    f.write_text("camera { position 1 2 3 }\n# comment line\nsphere { radius 99 }\n")
+    s = rt.parse_scene(f)
+    assert s.c.nObjects == 3 and s.c.objects[0].sphr_obj.radius == np.float32(1.15)
+    with pytest.raises(OSError):
+        rt.parse_scene(tmp_path / "missing")
+
+
+def test_product_package_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under raytracer_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "raytracer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        if "build" in dirpath:
+            continue
+        for fn in files:
+            if fn.endswith((".py", ".c", ".h", ".hip", ".cpp")) or fn == "Makefile":
+                text = open(os.path.join(dirpath, fn), errors="replace").read()
+                assert "oracle" not in text.lower(), f"{fn} mentions the oracle"
+    out = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "libref" not in out

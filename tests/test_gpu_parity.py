@@ -1,0 +1,308 @@
+"""GPU parity tests proper: the HIP path, called through the C-ABI (librt_hip.so), against the
+CPU oracle on the same seeded inputs and against the committed fixtures of the reference.
+
+Tolerances (north_star): 8-bit RGB within +-1 LSB on >= 99.9 % of pixels; per-pixel float radiance
+relative error <= 1e-4 (checked on >= 99.9 % of pixels - a silhouette sample that flips between a
+hit and a miss changes its pixel by far more than any tolerance, on the CPU across compilers too:
+SURVEY.md appendix C.1).  In practice the kernels reproduce the reference's float operations one by
+one and the observed median error is 0.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+from conftest import parity_report, ppm_md5, rgb_bytes
+from oracle import oracle_py as O
+from raytracer_amd import _abi as A
+from raytracer_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+LSB_FRAC = 0.999   # fraction of pixels within +-1 LSB
+REL_FRAC = 0.999   # fraction of pixels with relative radiance error <= 1e-4
+
+
+def assert_parity(argb, rad, a_ref, r_ref, what=""):
+    lsb_ok, rel_ok, med, exact = parity_report(argb, rad, a_ref, r_ref)
+    assert lsb_ok >= LSB_FRAC, f"{what}: only {lsb_ok:.5f} of pixels within 1 LSB"
+    assert rel_ok >= REL_FRAC, f"{what}: only {rel_ok:.5f} of pixels within 1e-4 relative"
+    assert med <= 1e-6, f"{what}: median relative error {med}"
+    return exact
+
+
+def rays_of(st):
+    return st.primary_rays + st.shadow_rays + st.reflection_rays + st.transmission_rays
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+# ---------------------------------------------------------------------------------------------
+# host-pointer entry points (rt_hip_render / raytrace)
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("idx", range(7))
+def test_small_frames_against_reference_fixtures(golden, make_scene, idx):
+    meta, arrays = golden
+    fr = meta["small_frames"][idx]
+    sc = make_scene(fr["scene"])
+    cam = rt.prepare_camera(sc, fr["W"], fr["H"], fr["sqrtSpp"], fr["depth"])
+    argb, rad = rt.render(sc, cam)
+    assert_parity(argb, rad, arrays[fr["key"] + "_argb"], arrays[fr["key"] + "_rad"], fr["key"])
+
+
+@pytest.mark.parametrize("name,W,H,s,d", [
+    ("builtin", 640, 480, 1, 4),      # BASELINE config 1
+    ("builtin", 333, 217, 3, 5),      # ragged: neither dimension a multiple of the 32x8 block
+    ("builtin", 1, 1, 1, 2), ("builtin", 7, 3, 2, 0), ("builtin", 33, 9, 1, 16),
+    ("syn64", 160, 120, 2, 4), ("syn300", 128, 96, 1, 6), ("syn3000", 64, 48, 1, 3),
+])
+def test_against_oracle(make_scene, name, W, H, s, d):
+    sc = make_scene(name)
+    cam = rt.prepare_camera(sc, W, H, s, d)
+    argb, rad = rt.render(sc, cam)
+    a_o, r_o, _ = O.render(sc.c, cam, nthreads=16)
+    if W * H < 1000:  # tiny frames: every pixel must be within tolerance
+        assert (np.abs(rgb_bytes(argb) - rgb_bytes(a_o)) <= 1).all()
+        assert np.allclose(rad, r_o, rtol=1e-4, atol=1e-7)
+    else:
+        assert_parity(argb, rad, a_o, r_o, f"{name} {W}x{H}")
+
+
+def test_raytrace_drop_in_entry_matches_reference_hash(golden):
+    """raytrace() with the reference's own signature and main.c:159-160's arguments."""
+    meta, arrays = golden
+    sc = rt.Scene.builtin()
+    W, H = 640, 480
+    buf = np.zeros(W * H, dtype=np.uint32)
+    rt.raytrace(buf, sc, 45.0, W / H, 1.0, 200.0, W, H, 1, 4)
+    want = arrays["builtin_640x480_s1_d4_argb"].reshape(-1)
+    diff = np.abs(rgb_bytes(buf) - rgb_bytes(want)).max(-1)
+    assert (diff <= 1).mean() >= LSB_FRAC
+    assert (buf >> 24 == 0xFF).all()
+    # prepare_scene's side effect on the caller's scene (raytrace.c:77-84)
+    prep = [p for p in meta["prepare_scene"] if p[:3] == [640, 480, 1]][0]
+    got = np.array([sc.c.viewDistance, sc.c.viewPlaneHalfWidth, sc.c.viewPlaneHalfHeight, sc.c.sppWidth], np.float32)
+    assert np.array_equal(got, np.array(prep[3:], np.float32))
+    assert (sc.c.frameBufferWidth, sc.c.frameBufferHeight, sc.c.sqrtSpp) == (640, 480, 1)
+
+
+def test_sparse_pixels_of_full_size_builtin_configs(golden, make_scene):
+    meta, arrays = golden
+    sc = make_scene("builtin")
+    for sp in meta["sparse"][:3]:
+        cam = rt.prepare_camera(sc, sp["W"], sp["H"], sp["sqrtSpp"], sp["depth"])
+        _, rad = rt.render(sc, cam)
+        xy, want = arrays[sp["key"] + "_xy"], arrays[sp["key"] + "_rad"]
+        got = rad[xy[:, 1], xy[:, 0]]
+        rel = (np.abs(got - want) / np.maximum(np.abs(want), 1e-3)).max(-1)
+        assert (rel <= 1e-4).mean() >= 0.99, sp["key"]
+
+
+def test_empty_scene_and_no_lights():
+    sc = rt.Scene.builtin()
+    n_obj, n_l = sc.c.nObjects, sc.c.nLights
+    cam = rt.prepare_camera(sc, 40, 24, 2, 3)
+    try:
+        sc.c.nLights = 0                       # ambient only
+        argb, rad = rt.render(sc, cam)
+        a_o, r_o, _ = O.render(sc.c, cam)
+        assert np.allclose(rad, r_o, rtol=1e-4, atol=1e-7)
+        sc.c.nObjects = 0                      # nothing to hit: background everywhere
+        argb, rad = rt.render(sc, cam)
+        assert np.allclose(rad, np.array([sc.c.bgColor.r, sc.c.bgColor.g, sc.c.bgColor.b], np.float32), rtol=1e-6)
+    finally:
+        sc.c.nObjects, sc.c.nLights = n_obj, n_l
+
+
+def test_argument_errors():
+    sc = rt.Scene.builtin()
+    cam = rt.prepare_camera(sc, 16, 8, 1, 63)       # deeper than RT_MAX_LEVELS-2
+    with pytest.raises(rt.RtHipError):
+        rt.render(sc, cam)
+    cam = rt.prepare_camera(sc, 16, 8, 1, 2)
+    with pytest.raises(rt.RtHipError):
+        rt.render(sc, cam, row0=4, nrows=8)          # rows outside the frame
+    ctx = rt.Context(queue_cap=4096)
+    with pytest.raises(rt.RtHipError):
+        ctx.render_rows(cam, 1234)                   # no scene uploaded
+    ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# device-resident interface
+# ---------------------------------------------------------------------------------------------
+
+def render_dev(torch, ctx, cam, row0=0, nrows=None, stats=False):
+    W, H = cam.frameBufferWidth, cam.frameBufferHeight
+    argb = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    rad = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    if stats:
+        st = ctx.render_stats(cam, argb.data_ptr(), rad.data_ptr(), row0, nrows)
+    else:
+        ctx.render_rows(cam, argb.data_ptr(), rad.data_ptr(), row0, nrows, torch.cuda.current_stream().cuda_stream)
+        st = ctx.finish()
+    return argb.cpu().numpy().view(np.uint32), rad.cpu().numpy(), st
+
+
+def test_c2_full_frame_parity_counts_and_hash(torch_cuda, golden, make_scene):
+    """BASELINE config 2 (1920x1080, 4x4 spp, depth 8) at full size against the oracle and against
+    the reference's recorded ray / test counts."""
+    meta, _ = golden
+    fr = [f for f in meta["frames"] if f["W"] == 1920][0]
+    sc = make_scene("builtin")
+    cam = rt.prepare_camera(sc, 1920, 1080, 4, 8)
+    ctx = rt.Context()
+    ctx.upload(sc)
+    argb, rad, st = render_dev(torch_cuda, ctx, cam)
+    a_o, r_o, c_o = O.render(sc.c, cam, nthreads=16)
+    exact = assert_parity(argb, rad, a_o, r_o, "C2")
+    assert exact > 0.8
+    assert (argb != a_o).mean() < 1e-4            # 8-bit image: all but a handful of pixels identical
+    # counts: deterministic functions of scene + camera; a flipped silhouette sample moves them by a few
+    ref_rays = fr["counts"]["ray_create"] + fr["counts"]["ray_tinypush"] - (fr["counts"]["ray_create"] - 1920 * 1080 * 16)
+    assert abs(rays_of(st) - ref_rays) <= 64
+    assert st.primary_rays == 1920 * 1080 * 16
+    assert abs(st.shadow_rays - c_o["shadow_rays"]) <= 64
+    assert abs(st.reflection_rays - c_o["reflection_rays"]) <= 64
+    assert abs(st.transmission_rays - c_o["transmission_rays"]) <= 64
+    # instrumented kernels: algorithmic test counts equal the reference's wrap counters
+    argb2, rad2, st2 = render_dev(torch_cuda, ctx, cam, stats=True)
+    assert np.array_equal(argb2, argb) and np.array_equal(rad2.view(np.uint32), rad.view(np.uint32))
+    assert abs(st2.sphere_tests - fr["counts"]["sphere_tests"]) <= 256
+    assert abs(st2.sphere_hits - fr["counts"]["sphere_hits"]) <= 256
+    assert abs(st2.polygon_tests - fr["counts"]["polygon_tests"]) <= 256
+    assert abs(st2.polygon_hits - fr["counts"]["polygon_hits"]) <= 256
+    assert st2.k0_sphere_tests == 2 * st.primary_rays + st2.k0_shadow_rays * 2 - st2.k0_nodes_sphere
+    ctx.close()
+
+
+def test_row_slabs_compose_the_frame_bit_exactly(torch_cuda, make_scene):
+    """Rendering a slab = the same rows of the full render (what multi-GPU row partitioning relies on),
+    also for slabs that do not start on an 8-row tile boundary."""
+    sc = make_scene("builtin")
+    cam = rt.prepare_camera(sc, 200, 120, 2, 5)
+    ctx = rt.Context(queue_cap=1 << 20)
+    ctx.upload(sc)
+    full_a, full_r, st_full = render_dev(torch_cuda, ctx, cam)
+    total = 0
+    for row0, nrows in [(0, 37), (37, 50), (87, 33)]:
+        a, r, st = render_dev(torch_cuda, ctx, cam, row0, nrows)
+        assert np.array_equal(a[row0:row0 + nrows], full_a[row0:row0 + nrows])
+        assert np.array_equal(r[row0:row0 + nrows].view(np.uint32), full_r[row0:row0 + nrows].view(np.uint32))
+        assert not a[:row0].any() and not a[row0 + nrows:].any()
+        total += rays_of(st)
+    assert total == rays_of(st_full)
+    ctx.close()
+
+
+def test_batching_and_overflow_retry_do_not_change_pixels(torch_cuda, make_scene):
+    sc = make_scene("builtin")
+    cam = rt.prepare_camera(sc, 256, 192, 2, 6)
+    big = rt.Context(queue_cap=1 << 22)
+    big.upload(sc)
+    a0, r0, st0 = render_dev(torch_cuda, big, cam)
+    assert st0.batches == 1 and st0.overflow_retries == 0
+    big.set_batch_samples(256 * 2 * 2 * 16)      # 16-row batches
+    a1, r1, st1 = render_dev(torch_cuda, big, cam)
+    assert st1.batches == 12 and np.array_equal(a1, a0) and np.array_equal(r1.view(np.uint32), r0.view(np.uint32))
+    assert rays_of(st1) == rays_of(st0)
+    big.close()
+    small = rt.Context(queue_cap=32768)           # 512 entries per shard: the first plans overflow
+    small.upload(sc)
+    small.set_batch_samples(1 << 30)
+    a2, r2, st2 = render_dev(torch_cuda, small, cam)
+    assert st2.overflow_retries > 0
+    assert np.array_equal(a2, a0) and np.array_equal(r2.view(np.uint32), r0.view(np.uint32))
+    assert rays_of(st2) == rays_of(st0)
+    small.close()
+
+
+def test_runs_are_deterministic(torch_cuda, make_scene):
+    sc = make_scene("syn64")
+    cam = rt.prepare_camera(sc, 192, 128, 2, 6)
+    ctx = rt.Context(queue_cap=1 << 21)
+    ctx.upload(sc)
+    a0, r0, _ = render_dev(torch_cuda, ctx, cam)
+    for _ in range(3):
+        a, r, _ = render_dev(torch_cuda, ctx, cam)
+        assert np.array_equal(a, a0) and np.array_equal(r.view(np.uint32), r0.view(np.uint32))
+    ctx.close()
+
+
+def test_supersampling_is_the_mean_of_its_samples(torch_cuda, make_scene):
+    """Size-independent property: a sqrtSpp = 2 frame equals the 2x2 box average of the sqrtSpp = 1
+    frame at twice the resolution only where the sample grids coincide - they do: sample (i,j) of
+    pixel (x,y) at W,s=2 sits where pixel (2x+i, 2y+1-j)... (the V axis grows upwards, raytrace.c:761-763)."""
+    sc = make_scene("builtin")
+    ctx = rt.Context(queue_cap=1 << 21)
+    ctx.upload(sc)
+    W, H = 160, 96
+    _, r2, _ = render_dev(torch_cuda, ctx, rt.prepare_camera(sc, W, H, 2, 3))
+    _, r1, _ = render_dev(torch_cuda, ctx, rt.prepare_camera(sc, 2 * W, 2 * H, 1, 3))
+    # sample j of row y looks UP from the row's base line: it coincides with fine row 2y+1-j shifted by one row
+    # fine row f has base v = (H - f)/H * halfH ; coarse row y sample j: (H/2 - y)/(H/2)*halfH + (j + .5)*spp
+    # => coincide when f = 2y - j  (and fine sample offset .5 fine-pixel = .25 coarse) - not identical grids,
+    # so compare only loosely: the frames must agree in the mean (a global sanity property).
+    box = r1.reshape(H, 2, W, 2, 3).mean((1, 3))
+    assert abs(float(box.mean()) - float(r2.mean())) < 5e-3
+    ctx.close()
+
+
+@pytest.mark.parametrize("name,W,H,s,d,idx", [("c4", 3840, 2160, 4, 8, 3)])
+def test_c4_sparse_pins_at_full_size(torch_cuda, golden, make_scene, name, W, H, s, d, idx):
+    """BASELINE config 4 (1024 spheres + 4 quads, 4K, 16 spp): rows holding the reference's
+    get_pixel_color pins are rendered at the real frame size and compared."""
+    meta, arrays = golden
+    sp = meta["sparse"][idx]
+    assert sp["scene"] == name
+    sc = make_scene(name)
+    cam = rt.prepare_camera(sc, W, H, s, d)
+    ctx = rt.Context(queue_cap=1 << 22)
+    ctx.upload(sc)
+    xy, want = arrays[sp["key"] + "_xy"][:16], arrays[sp["key"] + "_rad"][:16]
+    ok = 0
+    for (x, y), w in zip(xy, want):
+        _, rad, _ = render_dev(torch_cuda, ctx, cam, int(y), 1)
+        rel = np.abs(rad[y, x] - w) / np.maximum(np.abs(w), 1e-3)
+        ok += bool((rel <= 1e-4).all())
+    assert ok >= 15
+    ctx.close()
+
+
+def test_c5_sparse_pins_tiled_scene(torch_cuda, golden, make_scene):
+    """BASELINE config 5 (16 384 spheres in 8 LDS tiles, 8 lights, depth 16, 8K, 64 spp)."""
+    meta, arrays = golden
+    sp = meta["sparse"][4]
+    sc = make_scene("c5")
+    cam = rt.prepare_camera(sc, 7680, 4320, 8, 16)
+    ctx = rt.Context(queue_cap=1 << 22)
+    ctx.upload(sc)
+    xy, want = arrays[sp["key"] + "_xy"][:4], arrays[sp["key"] + "_rad"][:4]
+    for (x, y), w in zip(xy, want):
+        _, rad, _ = render_dev(torch_cuda, ctx, cam, int(y), 1)
+        rel = np.abs(rad[y, x] - w) / np.maximum(np.abs(w), 1e-3)
+        assert (rel <= 1e-4).all(), (x, y, rad[y, x], w)
+    ctx.close()
+
+
+def test_device_math_is_ieee(torch_cuda):
+    """The parity argument rests on IEEE-correct f32 sqrt / divide and on the double-precision
+    islands being evaluated in double on the device.  Direct lighting of the checkerboard floor and
+    the background exercise exactly those (ray generation, plane hit, angle sum, shadow rays against
+    both spheres, Phong with ke = 2): every such pixel must be BIT-exact, except a handful of polygon
+    edge samples (the angle sum uses float acos on the device)."""
+    sc = rt.Scene.builtin()
+    cam = rt.prepare_camera(sc, 640, 480, 1, 0)
+    argb, rad = rt.render(sc, cam)
+    a_o, r_o, _ = O.render(sc.c, cam, nthreads=16)
+    floor_or_bg = (r_o[..., 2] == 0) | np.isclose(r_o[..., 2], sc.c.bgColor.b)
+    assert floor_or_bg.sum() > 200000
+    exact = (rad.view(np.uint32) == r_o.view(np.uint32)).all(-1)
+    assert (~exact & floor_or_bg).sum() <= 4
