@@ -21,8 +21,9 @@
  * Numerics: compiled with -ffp-contract=off; every float op is individually rounded in the
  * order the reference's C expressions evaluate, sqrt/div are IEEE-correct (hipcc default), and
  * the reference's double-precision islands (sphere roots ray.c:217-218, refraction
- * raytrace.c:517-518, angle sum ray.c:98,169) are evaluated in double.  acos is evaluated in
- * float (acosf) and powf by the device libm - the only places results can differ in the last ulp.
+ * raytrace.c:517-518, angle sum ray.c:98,169) are evaluated in double.  acos is taken in float
+ * first and redone in double only next to the acceptance threshold; powf with an integral
+ * exponent is a double square-and-multiply chain (see polygon_inside / phong_pow).
  */
 #include "rt_device.h"
 
@@ -113,26 +114,71 @@ __device__ __forceinline__ float sphere_distance(float B, float det)
 
 /* ray.c:128-176: sum of the angles pt subtends with consecutive vertices, in double; inside
  * iff sum + .001 > 2*pi.  (v_i - pt) and its length are shared by the two edges that use them;
- * the values are identical to the reference's recomputation. */
-__device__ __forceinline__ bool polygon_inside(const float4 *vtx, uint32_t nv, float px, float py,
+ * the values are identical to the reference's recomputation.
+ *
+ * The cosines are formed in float exactly as the reference does (vec4_costheta).  The angles are
+ * first taken with the fast float acosf; the float and double sums differ by < 4e-6, so only when
+ * the float verdict is closer than 1e-4 to the threshold (a band a few micrometres wide around
+ * the polygon's acceptance contour) is the sum redone with double acos, the reference's own
+ * arithmetic (ray.c:142-145,160-163).  The decision therefore equals the reference's. */
+template <typename T>
+__device__ __forceinline__ T polygon_angle_sum(const float4 *vtx, uint32_t nv, float px, float py,
                                                float pz)
 {
     const float4 v0 = vtx[0];
     const float a0x = v0.x - px, a0y = v0.y - py, a0z = v0.z - pz;
     const float m0 = mag3(a0x, a0y, a0z);
     float ax = a0x, ay = a0y, az = a0z, ma = m0;
-    double total = 0.0;
+    T total = 0;
     for (uint32_t i = 1; i < nv; ++i) {
         const float4 v = vtx[i];
         const float bx = v.x - px, by = v.y - py, bz = v.z - pz;
         const float mb = mag3(bx, by, bz);
         const float c = dot3(ax, ay, az, bx, by, bz) / (ma * mb);
-        total += (double)acosf(c);
+        if constexpr (sizeof(T) == 8)
+            total += acos((double)c);
+        else
+            total += acosf(c);
         ax = bx; ay = by; az = bz; ma = mb;
     }
     const float c = dot3(ax, ay, az, a0x, a0y, a0z) / (ma * m0);
-    total += (double)acosf(c);
-    return (total + .001) > (2.0 * 3.14159265358979323846);
+    if constexpr (sizeof(T) == 8)
+        total += acos((double)c);
+    else
+        total += acosf(c);
+    return total;
+}
+
+__device__ __forceinline__ bool polygon_inside(const float4 *vtx, uint32_t nv, float px, float py,
+                                               float pz)
+{
+    const float twopi = 6.2831853071795864769f;
+    const float sf = polygon_angle_sum<float>(vtx, nv, px, py, pz);
+    const float margin = (sf + 0.001f) - twopi;
+    if (fabsf(margin) > 1e-4f) /* NaN (a cosine outside [-1,1]) falls through to the exact path */
+        return margin > 0.0f;
+    const double sd = polygon_angle_sum<double>(vtx, nv, px, py, pz);
+    return (sd + .001) > (2.0 * 3.14159265358979323846);
+}
+
+/* powf(s, ke) of raytrace.c:371.  glibc's powf evaluates in double and is correctly rounded in
+ * all but astronomically rare cases; for the usual integral shininess (ke = 2, 20, ...) the same
+ * value comes from a square-and-multiply chain in double (relative error < 2^-49) rounded once to
+ * float - exact where the device's float powf can be an ulp off, and much shorter.  Other
+ * exponents use the device powf (<= 1 ulp). */
+__device__ __forceinline__ float phong_pow(float s, float ke)
+{
+    const int e = (int)ke;
+    if ((float)e == ke && e >= 0 && e <= 4096) {
+        double r = 1.0, b = (double)s;
+        for (int k = e; k; k >>= 1) {
+            if (k & 1)
+                r *= b;
+            b *= b;
+        }
+        return (float)r;
+    }
+    return powf(s, ke);
 }
 
 /* Cooperative copy of n float4 from HBM to LDS by the whole block. */
@@ -439,7 +485,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
                 float s = dot3(Rx, Ry, Rz, Vx, Vy, Vz);
                 if (s < 0.0f)
                     s = 0.0f;
-                s = powf(s, mC.y);
+                s = phong_pow(s, mC.y);
                 spr += lc.x * s; spg += lc.y * s; spb += lc.z * s;
             }
         }
