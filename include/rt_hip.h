@@ -197,6 +197,17 @@ int  rt_hip_render_rows(rt_hip_ctx *ctx, const rt_camera *camera,
                         uint32_t *d_argb, float *d_radiance,
                         uint32_t row0, uint32_t nrows, void *stream);
 
+/* Multi-GPU partition (the Cell build's pixel-cyclic split, ppu/ppu_raytrace.c:237-263 and
+ * spu/spu_raytrace.c:559-565, at 8-row granularity): render the 8-row blocks b of the frame with
+ * b % nphases == phase into a COMPACT local buffer - block b lands in rows [8*(b/nphases), +8) of
+ * d_argb_local / d_radiance_local, which hold 8*ceil(ceil(H/8)/nphases) rows of `width` pixels.
+ * Cyclic blocks balance the very uneven cost of sky and sphere rows; an all-gather of the local
+ * buffers followed by one de-interleave copy rebuilds the frame.  Asynchronous like
+ * rt_hip_render_rows. */
+int  rt_hip_render_interleaved(rt_hip_ctx *ctx, const rt_camera *camera,
+                               uint32_t *d_argb_local, float *d_radiance_local,
+                               uint32_t phase, uint32_t nphases, void *stream);
+
 /* Wait for the last rt_hip_render_rows, verify no queue overflowed (re-rendering finer
  * batches if one did) and return its counters.  stats may be NULL. */
 int  rt_hip_finish(rt_hip_ctx *ctx, rt_hip_stats *stats);

@@ -130,6 +130,11 @@ class Context:
         check(load().rt_hip_render_rows(self._h, C.byref(cam), d_argb, d_radiance or None, row0, nrows,
                                         stream or None), "rt_hip_render_rows")
 
+    def render_interleaved(self, cam, d_argb_local, d_radiance_local=0, phase=0, nphases=1, stream=0):
+        """8-row blocks b with b % nphases == phase, into a compact local buffer (multi-GPU split)."""
+        check(load().rt_hip_render_interleaved(self._h, C.byref(cam), d_argb_local, d_radiance_local or None,
+                                               phase, nphases, stream or None), "rt_hip_render_interleaved")
+
     def finish(self):
         st = A.rt_hip_stats()
         check(load().rt_hip_finish(self._h, C.byref(st)), "rt_hip_finish")

@@ -37,9 +37,19 @@ void set_err(const char *fmt, ...)
 constexpr uint32_t kMaxBatches = 64;            /* counter slots per enqueue round */
 constexpr uint64_t kDefaultCap = 64ull << 20;   /* entries per queue / node pool   */
 
+/* a run of 8-row tile rows [t0,t1) of the current job, rendered as one image batch */
 struct Batch {
-    uint32_t y0, y1;
+    uint32_t t0, t1;
     uint32_t slot;
+};
+
+/* which frame rows a job covers (see DevRows in rt_device.h) */
+struct Job {
+    bool interleaved = false;
+    uint32_t row0 = 0, nrows = 0;    /* contiguous slab                           */
+    uint32_t phase = 0, nphases = 1; /* cyclic 8-row blocks: block b -> b % nphases */
+    uint32_t ntiles = 0;             /* tile rows of the whole job                */
+    bool stats = false;
 };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -67,9 +77,10 @@ struct rt_hip_ctx {
     DevCamera C{};
     uint32_t *d_argb = nullptr;
     float *d_rad = nullptr;
-    uint32_t row0 = 0, nrows = 0;
+    Job job;
     hipStream_t stream = nullptr;
-    std::vector<Batch> batches;
+    std::vector<Batch> batches;      /* batches in flight (enqueued, not yet checked) */
+    std::vector<Batch> todo;         /* batches still to enqueue                      */
     /* options */
     bool timing = false;
     uint64_t batch_samples = 0;
@@ -126,9 +137,28 @@ int ensure_pix(rt_hip_ctx *c, size_t npix)
     return 0;
 }
 
-/* enqueue one image batch: rows [y0,y1) */
+DevRows rows_of(const rt_hip_ctx *c, const Batch &b)
+{
+    const Job &j = c->job;
+    DevRows R;
+    R.ntiles = b.t1 - b.t0;
+    if (j.interleaved) {
+        R.y_first = (b.t0 * j.nphases + j.phase) * 8u;
+        R.y_step = 8u * j.nphases;
+        R.y_limit = c->C.H;
+        R.out_first = b.t0 * 8u;
+    } else {
+        R.y_first = R.out_first = j.row0 + 8u * b.t0;
+        R.y_step = 8u;
+        R.y_limit = j.row0 + j.nrows;
+    }
+    return R;
+}
+
+/* enqueue one image batch */
 int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
 {
+    const DevRows R = rows_of(c, b);
     DevWork Wk = c->W;
     Wk.pixAcc = c->pixAcc;
     Wk.counters = c->d_counters + (size_t)b.slot * c->cwords;
@@ -143,7 +173,7 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
         c->ev.push_back(e1);
         HIP_TRY(hipEventRecord(e0, st));
     }
-    rt_launch_primary(c->S, c->C, Wk, b.y0, b.y1, stats, st);
+    rt_launch_primary(c->S, c->C, Wk, R, stats, st);
     if (timed)
         HIP_TRY(hipEventRecord(c->ev.back(), st));
     const uint32_t depth = c->C.depth;
@@ -151,20 +181,18 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
         rt_launch_bounce(c->S, c->C, Wk, d, stats, st);
     for (uint32_t d = depth; d-- > 1;) /* nodes exist on levels 0..depth-1; level 0 folds in resolve */
         rt_launch_fold(Wk, d, st);
-    rt_launch_resolve(c->C, Wk, b.y0, b.y1, c->d_argb, c->d_rad, st);
+    rt_launch_resolve(c->C, Wk, R, c->d_argb, c->d_rad, st);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-uint32_t rows_per_batch(const rt_hip_ctx *c, uint64_t max_samples)
+uint32_t tiles_per_batch(const rt_hip_ctx *c, uint64_t max_samples)
 {
-    const uint64_t per_row = (uint64_t)c->C.W * c->C.sqrtSpp * c->C.sqrtSpp;
-    uint64_t rows = per_row ? max_samples / per_row : 1;
-    if (rows >= 8)
-        rows -= rows % 8; /* keep 8-row wave tiles whole */
-    if (rows < 1)
-        rows = 1;
-    return (uint32_t)(rows > 0xFFFFFFFFull ? 0xFFFFFFFFull : rows);
+    const uint64_t per_tile = 8ull * c->C.W * c->C.sqrtSpp * c->C.sqrtSpp;
+    uint64_t t = per_tile ? max_samples / per_tile : 1;
+    if (t < 1)
+        t = 1;
+    return (uint32_t)(t > 0x0FFFFFFFull ? 0x0FFFFFFFull : t);
 }
 
 bool batch_overflowed(const uint32_t *cnt)
@@ -217,59 +245,76 @@ void accumulate(rt_hip_stats &s, const uint32_t *cnt, uint32_t levels)
     s.k0_nodes_polygon += st[ST_K0_NODES_POLY];
 }
 
-/* Render rows [y0,y1) in batches of `rows` rows, wait, and re-render (halving the batch height)
- * every batch whose queues overflowed.  Adds the counters of the good batches to c->stats. */
-int render_range_sync(rt_hip_ctx *c, uint32_t y0, uint32_t y1, uint32_t rows, bool stats)
+/* Enqueue up to kMaxBatches batches of the work list (one counter slot each) and the copy of
+ * their counters to the pinned mirror.  Asynchronous. */
+int enqueue_round(rt_hip_ctx *c)
 {
-    std::vector<Batch> todo;
-    for (uint32_t y = y0; y < y1;) {
-        const uint32_t ye = (y1 - y > rows) ? y + rows : y1;
-        todo.push_back({y, ye, 0});
-        y = ye;
+    c->batches.clear();
+    while (!c->todo.empty() && c->batches.size() < kMaxBatches) {
+        Batch b = c->todo.back();
+        c->todo.pop_back();
+        b.slot = (uint32_t)c->batches.size();
+        int rc = enqueue_batch(c, b, c->job.stats);
+        if (rc)
+            return rc;
+        c->batches.push_back(b);
     }
-    size_t done = 0;
-    while (done < todo.size()) {
-        const size_t n = std::min<size_t>(todo.size() - done, kMaxBatches);
-        for (size_t i = 0; i < n; ++i) {
-            todo[done + i].slot = (uint32_t)i;
-            int rc = enqueue_batch(c, todo[done + i], stats);
-            if (rc)
-                return rc;
-        }
-        HIP_TRY(hipMemcpyAsync(c->h_counters, c->d_counters, n * c->cwords * sizeof(uint32_t),
-                               hipMemcpyDeviceToHost, c->stream));
+    if (!c->batches.empty())
+        HIP_TRY(hipMemcpyAsync(c->h_counters, c->d_counters,
+                               c->batches.size() * c->cwords * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                               c->stream));
+    return 0;
+}
+
+/* Wait for the round in flight; batches whose queues overflowed go back on the work list as two
+ * halves, the others add their counters to the statistics.  Repeats until the list is empty. */
+int drain(rt_hip_ctx *c)
+{
+    for (;;) {
         HIP_TRY(hipStreamSynchronize(c->stream));
-        for (size_t i = 0; i < n; ++i) {
-            const Batch &b = todo[done + i];
+        for (size_t i = 0; i < c->batches.size(); ++i) {
+            const Batch &b = c->batches[i];
             const uint32_t *cnt = c->h_counters + i * c->cwords;
             if (batch_overflowed(cnt)) {
-                const uint32_t h = b.y1 - b.y0;
-                if (h <= 1) {
-                    set_err("ray/node queues (%llu entries) overflow on a single row; raise the capacity",
+                const uint32_t n = b.t1 - b.t0;
+                if (n <= 1) {
+                    set_err("ray/node queues (%llu entries) overflow on a single 8-row tile row; raise the capacity",
                             (unsigned long long)c->cap);
+                    c->batches.clear();
+                    c->todo.clear();
                     return RT_E_OVERFLOW;
                 }
                 c->stats.overflow_retries++;
-                /* cannot recurse while h_counters of this round is still being read: copy first */
-                std::vector<uint32_t> keep(c->h_counters, c->h_counters + n * c->cwords);
-                int rc = render_range_sync(c, b.y0, b.y1, (h + 1) / 2, stats);
-                memcpy(c->h_counters, keep.data(), keep.size() * sizeof(uint32_t));
-                if (rc)
-                    return rc;
+                const uint32_t mid = b.t0 + n / 2;
+                c->todo.push_back({mid, b.t1, 0});
+                c->todo.push_back({b.t0, mid, 0});
             } else {
                 accumulate(c->stats, cnt, c->C.depth + 1);
                 c->stats.batches++;
             }
         }
-        done += n;
+        c->batches.clear();
+        if (c->todo.empty())
+            return 0;
+        int rc = enqueue_round(c);
+        if (rc)
+            return rc;
     }
-    return 0;
 }
 
 void finish_stats(rt_hip_ctx *c)
 {
     rt_hip_stats &s = c->stats;
-    s.primary_rays = (uint64_t)c->C.W * c->nrows * c->C.sqrtSpp * c->C.sqrtSpp;
+    const Job &j = c->job;
+    uint64_t rows = j.nrows;
+    if (j.interleaved) {
+        rows = 0;
+        for (uint32_t t = 0; t < j.ntiles; ++t) {
+            const uint32_t y = (t * j.nphases + j.phase) * 8u;
+            rows += (c->C.H - y < 8u) ? c->C.H - y : 8u;
+        }
+    }
+    s.primary_rays = (uint64_t)c->C.W * rows * c->C.sqrtSpp * c->C.sqrtSpp;
     s.shadow_rays = s.shade_nodes * c->S.nLights;
     s.k0_shadow_rays = s.k0_shade_nodes * c->S.nLights;
 }
@@ -387,7 +432,7 @@ void rt_hip_ctx_destroy(rt_hip_ctx *c)
     if (!c)
         return;
     (void)hipSetDevice(c->device);
-    if (c->pending && c->stream)
+    if (c->pending)
         (void)hipStreamSynchronize(c->stream);
     drop_events(c);
     if (c->scene_blob) (void)hipFree(c->scene_blob);
@@ -532,13 +577,12 @@ int rt_hip_scene_upload(rt_hip_ctx *c, const rt_scene *sc)
     return 0;
 }
 
-int rt_hip_render_rows(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb, float *d_rad,
-                       uint32_t row0, uint32_t nrows, void *stream)
+/* common part of the three device-resident render entry points: plan the batches, enqueue the
+ * first round */
+static int submit(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb, float *d_rad, const Job &job,
+                  void *stream)
 {
-    int rc = check_args(c, cam, d_argb, row0, nrows);
-    if (rc)
-        return rc;
-    rc = ctx_set_device(c);
+    int rc = ctx_set_device(c);
     if (rc)
         return rc;
     if (c->pending) { /* the previous render's counters were never collected: drain it */
@@ -551,41 +595,58 @@ int rt_hip_render_rows(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb, fl
     c->cwords = RT_COUNTER_WORDS_FOR(cam->depth + 2);
     c->d_argb = d_argb;
     c->d_rad = d_rad;
-    c->row0 = row0;
-    c->nrows = nrows;
+    c->job = job;
     c->stream = (hipStream_t)stream;
-    c->pending_stats = false;
     c->batches.clear();
+    c->todo.clear();
     drop_events(c);
     memset(&c->stats, 0, sizeof c->stats);
-    if (nrows == 0) {
-        c->pending = true;
+    c->pending = true;
+    if (job.ntiles == 0)
         return 0;
-    }
-    const uint32_t rows = rows_per_batch(c, default_batch_samples(c));
-    const uint32_t brow = rows < nrows ? rows : nrows;
-    rc = ensure_pix(c, (size_t)brow * c->C.W);
+    const uint32_t per = tiles_per_batch(c, default_batch_samples(c));
+    const uint32_t most = per < job.ntiles ? per : job.ntiles;
+    rc = ensure_pix(c, (size_t)most * 8u * c->C.W);
     if (rc)
         return rc;
-    uint32_t slot = 0;
-    for (uint32_t y = row0; y < row0 + nrows;) {
-        const uint32_t ye = (row0 + nrows - y > rows) ? y + rows : row0 + nrows;
-        if (slot == kMaxBatches) { /* out of counter slots: collect what is queued so far */
-            set_err("render needs more than %u batches; raise the queue capacity", kMaxBatches);
-            return RT_E_INVALID;
-        }
-        Batch b{y, ye, slot++};
-        c->batches.push_back(b);
-        rc = enqueue_batch(c, b, false);
-        if (rc)
-            return rc;
-        y = ye;
+    for (uint32_t t = job.ntiles; t > 0;) { /* pushed back to front: the list is popped from the end */
+        const uint32_t n = (t % per) ? (t % per) : per;
+        c->todo.push_back({t - n, t, 0});
+        t -= n;
     }
-    HIP_TRY(hipMemcpyAsync(c->h_counters, c->d_counters,
-                           c->batches.size() * c->cwords * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                           c->stream));
-    c->pending = true;
-    return 0;
+    return enqueue_round(c);
+}
+
+int rt_hip_render_rows(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb, float *d_rad,
+                       uint32_t row0, uint32_t nrows, void *stream)
+{
+    int rc = check_args(c, cam, d_argb, row0, nrows);
+    if (rc)
+        return rc;
+    Job job;
+    job.row0 = row0;
+    job.nrows = nrows;
+    job.ntiles = (nrows + 7u) / 8u;
+    return submit(c, cam, d_argb, d_rad, job, stream);
+}
+
+int rt_hip_render_interleaved(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb_local,
+                              float *d_rad_local, uint32_t phase, uint32_t nphases, void *stream)
+{
+    int rc = check_args(c, cam, d_argb_local, 0, 0);
+    if (rc)
+        return rc;
+    if (nphases == 0 || phase >= nphases) {
+        set_err("phase %u of %u", phase, nphases);
+        return RT_E_INVALID;
+    }
+    const uint32_t nblocks = (cam->frameBufferHeight + 7u) / 8u;
+    Job job;
+    job.interleaved = true;
+    job.phase = phase;
+    job.nphases = nphases;
+    job.ntiles = phase < nblocks ? (nblocks - phase + nphases - 1u) / nphases : 0u;
+    return submit(c, cam, d_argb_local, d_rad_local, job, stream);
 }
 
 int rt_hip_finish(rt_hip_ctx *c, rt_hip_stats *stats)
@@ -594,56 +655,32 @@ int rt_hip_finish(rt_hip_ctx *c, rt_hip_stats *stats)
         set_err("null argument");
         return RT_E_INVALID;
     }
-    if (!c->pending) {
-        if (stats)
-            *stats = c->stats;
-        return 0;
-    }
-    int rc = ctx_set_device(c);
-    if (rc)
-        return rc;
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    c->pending = false;
-    /* timing of the fused primary kernel */
-    for (size_t i = 0; i + 1 < c->ev.size(); i += 2) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess) {
-            c->stats.k0_ms += ms;
-            c->stats.k0_launches++;
-        }
-    }
-    drop_events(c);
-    std::vector<Batch> redo;
-    std::vector<uint32_t> snap(c->h_counters, c->h_counters + c->batches.size() * c->cwords);
-    for (size_t i = 0; i < c->batches.size(); ++i) {
-        const uint32_t *cnt = snap.data() + i * c->cwords;
-        if (batch_overflowed(cnt)) {
-            redo.push_back(c->batches[i]);
-        } else {
-            accumulate(c->stats, cnt, c->C.depth + 1);
-            c->stats.batches++;
-        }
-    }
-    const bool was_timing = c->timing;
-    c->timing = false;
-    for (const Batch &b : redo) {
-        const uint32_t h = b.y1 - b.y0;
-        if (h <= 1) {
-            set_err("ray/node queues (%llu entries) overflow on a single row; raise the capacity",
-                    (unsigned long long)c->cap);
-            c->timing = was_timing;
-            return RT_E_OVERFLOW;
-        }
-        c->stats.overflow_retries++;
-        rc = render_range_sync(c, b.y0, b.y1, (h + 1) / 2, false);
-        if (rc) {
-            c->timing = was_timing;
+    if (c->pending) {
+        int rc = ctx_set_device(c);
+        if (rc)
             return rc;
+        const bool was_timing = c->timing;
+        /* only the first round is timed; re-rendered batches are not */
+        std::vector<hipEvent_t> ev;
+        ev.swap(c->ev);
+        c->timing = false;
+        rc = drain(c);
+        c->timing = was_timing;
+        c->pending = false;
+        for (size_t i = 0; i + 1 < ev.size(); i += 2) {
+            float ms = 0.f;
+            if (rc == 0 && hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) {
+                c->stats.k0_ms += ms;
+                c->stats.k0_launches++;
+            }
         }
+        for (hipEvent_t e : ev)
+            (void)hipEventDestroy(e);
+        drop_events(c);
+        if (rc)
+            return rc;
+        finish_stats(c);
     }
-    c->timing = was_timing;
-    c->batches.clear();
-    finish_stats(c);
     if (stats)
         *stats = c->stats;
     return 0;
@@ -655,37 +692,15 @@ int rt_hip_render_stats(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb, f
     int rc = check_args(c, cam, d_argb, row0, nrows);
     if (rc)
         return rc;
-    rc = ctx_set_device(c);
+    Job job;
+    job.row0 = row0;
+    job.nrows = nrows;
+    job.ntiles = (nrows + 7u) / 8u;
+    job.stats = true;
+    rc = submit(c, cam, d_argb, d_rad, job, stream);
     if (rc)
         return rc;
-    if (c->pending) {
-        rc = rt_hip_finish(c, nullptr);
-        if (rc)
-            return rc;
-    }
-    c->cam = *cam;
-    fold_camera(c->C, *cam);
-    c->cwords = RT_COUNTER_WORDS_FOR(cam->depth + 2);
-    c->d_argb = d_argb;
-    c->d_rad = d_rad;
-    c->row0 = row0;
-    c->nrows = nrows;
-    c->stream = (hipStream_t)stream;
-    memset(&c->stats, 0, sizeof c->stats);
-    if (nrows) {
-        const uint32_t rows = rows_per_batch(c, default_batch_samples(c));
-        const uint32_t brow = rows < nrows ? rows : nrows;
-        rc = ensure_pix(c, (size_t)brow * c->C.W);
-        if (rc)
-            return rc;
-        rc = render_range_sync(c, row0, row0 + nrows, rows, true);
-        if (rc)
-            return rc;
-    }
-    finish_stats(c);
-    if (stats)
-        *stats = c->stats;
-    return 0;
+    return rt_hip_finish(c, stats);
 }
 
 /* ---- host-pointer entry points ---------------------------------------------------------- */

@@ -49,6 +49,16 @@ struct DevScene {
     float ambient[3];
 };
 
+/* Rows of one image batch, as 8-row tile rows (a wave owns an 8x8 pixel tile).
+ * Tile row j of the batch covers frame rows y_first + j*y_step + [0,8), clipped to y_limit, and
+ * is written to output rows out_first + 8*j + [0,8).
+ *   contiguous slab [row0,row0+n): y_first = out_first = row0 + 8*t0, y_step = 8, y_limit = row0+n
+ *   cyclic 8-row blocks (phase r of N ranks, multi-GPU): y_first = (t0*N + r)*8, y_step = 8*N,
+ *   y_limit = H, out_first = 8*t0 (rows of the rank's compact local buffer)               */
+struct DevRows {
+    uint32_t y_first, y_step, y_limit, out_first, ntiles;
+};
+
 /* Per-batch work state in HBM. */
 struct DevWork {
     float4 *qA[2];        /* ray queues, ping-pong by level parity: (ox,oy,oz,magnitude) */
@@ -107,11 +117,11 @@ enum {
 static_assert(2 * ST_COUNT <= CNT_STATS_STRIDE, "statistics do not fit their line");
 
 /* launch wrappers implemented in rt_kernels.hip (all asynchronous on `stream`) */
-void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t y0,
-                       uint32_t y1, bool stats, hipStream_t stream);
+void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
+                       bool stats, hipStream_t stream);
 void rt_launch_bounce(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t level,
                       bool stats, hipStream_t stream);
 void rt_launch_fold(const DevWork &Wk, uint32_t level, hipStream_t stream);
-void rt_launch_resolve(const DevCamera &C, const DevWork &Wk, uint32_t y0, uint32_t y1,
-                       uint32_t *d_argb, float *d_radiance, hipStream_t stream);
+void rt_launch_resolve(const DevCamera &C, const DevWork &Wk, const DevRows &R, uint32_t *d_argb,
+                       float *d_radiance, hipStream_t stream);
 size_t rt_scene_lds_bytes(const DevScene &S);

@@ -606,7 +606,7 @@ __device__ __forceinline__ void flush_tally(uint64_t *st, Tally<STATS> &tl, bool
 /* ------------------------------------------------------------------------------------------ */
 template <bool TILED, bool STATS>
 __global__ __launch_bounds__(RT_BLOCK) void k_primary(DevScene S, DevCamera C, DevWork Wk,
-                                                      uint32_t y0, uint32_t y1)
+                                                      DevRows R)
 {
     extern __shared__ __attribute__((aligned(16))) float4 lds[];
     float4 *lds_poly = lds;
@@ -619,14 +619,16 @@ __global__ __launch_bounds__(RT_BLOCK) void k_primary(DevScene S, DevCamera C, D
     /* a wave owns an 8x8 pixel tile; the block is 4 tiles side by side (32x8 pixels) */
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t x = blockIdx.x * 32u + wv * 8u + (lane & 7u);
-    const uint32_t y = y0 + blockIdx.y * 8u + (lane >> 3);
-    const bool valid = (x < C.W) && (y < y1);
+    const uint32_t y = R.y_first + blockIdx.y * R.y_step + (lane >> 3);
+    const bool valid = (x < C.W) && (y < R.y_limit);
 
     /* raytrace.c:755-763: the pixel-dependent part of the U and V shifts */
     const float fu0 = (((float)x - C.hfbW) / C.hfbW) * C.halfW;
     const float fv0 = ((C.hfbH - (float)y) / C.hfbH) * C.halfH;
 
-    const uint32_t shard = (blockIdx.y * gridDim.x + blockIdx.x) % RT_SHARDS;
+    /* every wave feeds its own shard: even a single tile row spreads over all of them */
+    const uint32_t shard = ((blockIdx.y * gridDim.x + blockIdx.x) * (RT_BLOCK / 64u) +
+                            (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) % RT_SHARDS;
     const uint32_t node_base = shard * Wk.capS; /* level 0 opens every shard's node range */
 
     float accr = 0.0f, accg = 0.0f, accb = 0.0f; /* color_init raytrace.c:908 */
@@ -670,7 +672,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_primary(DevScene S, DevCamera C, D
         }
     }
     if (valid)
-        Wk.pixAcc[(size_t)(y - y0) * C.W + x] = make_float4(accr, accg, accb, __uint_as_float(head));
+        Wk.pixAcc[(size_t)(blockIdx.y * 8u + (lane >> 3)) * C.W + x] =
+            make_float4(accr, accg, accb, __uint_as_float(head));
 
     uint64_t *st = (uint64_t *)(Wk.counters + CNT_STATS + shard * CNT_STATS_STRIDE);
     wave_add_stat(st, ST_K0_SHADE_NODES, sc.shade_nodes);
@@ -794,13 +797,16 @@ __global__ __launch_bounds__(RT_BLOCK) void k_fold(DevWork Wk, uint32_t level)
 
 /* k_resolve: per pixel - fold this pixel's depth-0 roots, add them to the in-register sum of
  * the childless samples, scale (raytrace.c:779), store radiance, pack (raytrace.c:783-790). */
-__global__ __launch_bounds__(RT_BLOCK) void k_resolve(DevCamera C, DevWork Wk, uint32_t y0, uint32_t y1,
+__global__ __launch_bounds__(RT_BLOCK) void k_resolve(DevCamera C, DevWork Wk, DevRows R,
                                                       uint32_t *argb, float *radiance)
 {
     if (overflowed_before(Wk.counters, RT_MAX_LEVELS))
         return; /* rows of an abandoned batch are rendered again by the host in smaller batches */
-    const size_t npix = (size_t)(y1 - y0) * C.W;
+    const size_t npix = (size_t)R.ntiles * 8u * C.W;
     for (size_t p = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x; p < npix; p += (size_t)gridDim.x * RT_BLOCK) {
+        const uint32_t row = (uint32_t)(p / C.W); /* row of the batch: tile row*8 + line */
+        if (R.y_first + (row >> 3) * R.y_step + (row & 7u) >= R.y_limit)
+            continue; /* the last tile row of a slab may hang over its end */
         const float4 acc = Wk.pixAcc[p];
         float r = acc.x, g = acc.y, b = acc.z;
         uint32_t root = __float_as_uint(acc.w);
@@ -812,7 +818,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DevCamera C, DevWork Wk, u
             root = __float_as_uint(Cc.w) >> 3;
         }
         r = r * C.scale; g = g * C.scale; b = b * C.scale;
-        const size_t o = (size_t)y0 * C.W + p;
+        const size_t o = (size_t)R.out_first * C.W + p;
         if (radiance) {
             radiance[3 * o + 0] = r; radiance[3 * o + 1] = g; radiance[3 * o + 2] = b;
         }
@@ -836,18 +842,18 @@ size_t rt_scene_lds_bytes(const DevScene &S)
     return (size_t)(S.nPolySlots + sph) * sizeof(float4);
 }
 
-void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t y0,
-                       uint32_t y1, bool stats, hipStream_t stream)
+void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
+                       bool stats, hipStream_t stream)
 {
-    const dim3 grid((C.W + 31u) / 32u, (y1 - y0 + 7u) / 8u);
+    const dim3 grid((C.W + 31u) / 32u, R.ntiles);
     const size_t lds = rt_scene_lds_bytes(S);
     const bool tiled = S.nSph > RT_TILE_SPHERES;
     if (tiled) {
-        if (stats) k_primary<true, true><<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, y0, y1);
-        else       k_primary<true, false><<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, y0, y1);
+        if (stats) k_primary<true, true><<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, R);
+        else       k_primary<true, false><<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, R);
     } else {
-        if (stats) k_primary<false, true><<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, y0, y1);
-        else       k_primary<false, false><<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, y0, y1);
+        if (stats) k_primary<false, true><<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, R);
+        else       k_primary<false, false><<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, R);
     }
 }
 
@@ -882,14 +888,14 @@ void rt_launch_fold(const DevWork &Wk, uint32_t level, hipStream_t stream)
     k_fold<<<queue_grid(Wk), RT_BLOCK, 0, stream>>>(Wk, level);
 }
 
-void rt_launch_resolve(const DevCamera &C, const DevWork &Wk, uint32_t y0, uint32_t y1,
-                       uint32_t *d_argb, float *d_radiance, hipStream_t stream)
+void rt_launch_resolve(const DevCamera &C, const DevWork &Wk, const DevRows &R, uint32_t *d_argb,
+                       float *d_radiance, hipStream_t stream)
 {
-    const size_t npix = (size_t)(y1 - y0) * C.W;
+    const size_t npix = (size_t)R.ntiles * 8u * C.W;
     size_t grid = (npix + RT_BLOCK - 1) / RT_BLOCK;
     if (grid > 4096)
         grid = 4096;
     if (grid == 0)
         grid = 1;
-    k_resolve<<<(uint32_t)grid, RT_BLOCK, 0, stream>>>(C, Wk, y0, y1, d_argb, d_radiance);
+    k_resolve<<<(uint32_t)grid, RT_BLOCK, 0, stream>>>(C, Wk, R, d_argb, d_radiance);
 }

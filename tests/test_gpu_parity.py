@@ -204,24 +204,58 @@ def test_row_slabs_compose_the_frame_bit_exactly(torch_cuda, make_scene):
 
 def test_batching_and_overflow_retry_do_not_change_pixels(torch_cuda, make_scene):
     sc = make_scene("builtin")
-    cam = rt.prepare_camera(sc, 256, 192, 2, 6)
-    big = rt.Context(queue_cap=1 << 22)
+    cam = rt.prepare_camera(sc, 1024, 768, 2, 6)
+    big = rt.Context(queue_cap=1 << 24)
     big.upload(sc)
     a0, r0, st0 = render_dev(torch_cuda, big, cam)
     assert st0.batches == 1 and st0.overflow_retries == 0
-    big.set_batch_samples(256 * 2 * 2 * 16)      # 16-row batches
+    big.set_batch_samples(1024 * 2 * 2 * 16)     # 16-row batches (two tile rows)
     a1, r1, st1 = render_dev(torch_cuda, big, cam)
-    assert st1.batches == 12 and np.array_equal(a1, a0) and np.array_equal(r1.view(np.uint32), r0.view(np.uint32))
+    assert st1.batches == 48 and np.array_equal(a1, a0) and np.array_equal(r1.view(np.uint32), r0.view(np.uint32))
     assert rays_of(st1) == rays_of(st0)
     big.close()
-    small = rt.Context(queue_cap=32768)           # 512 entries per shard: the first plans overflow
+    small = rt.Context(queue_cap=1 << 18)         # 4096 entries per shard: the first plans overflow
     small.upload(sc)
     small.set_batch_samples(1 << 30)
     a2, r2, st2 = render_dev(torch_cuda, small, cam)
-    assert st2.overflow_retries > 0
+    assert st2.overflow_retries > 0 and st2.batches > 1
     assert np.array_equal(a2, a0) and np.array_equal(r2.view(np.uint32), r0.view(np.uint32))
     assert rays_of(st2) == rays_of(st0)
     small.close()
+    tiny = rt.Context(queue_cap=1024)             # cannot hold even one tile row: a clean error, no fault
+    tiny.upload(sc)
+    with pytest.raises(rt.RtHipError):
+        render_dev(torch_cuda, tiny, cam)
+    tiny.close()
+
+
+def test_interleaved_blocks_rebuild_the_frame(torch_cuda, make_scene):
+    """rt_hip_render_interleaved: cyclic 8-row blocks into compact local buffers (the multi-GPU
+    partition), here all phases on one GPU; de-interleaving must give the full render bit-exactly."""
+    torch = torch_cuda
+    sc = make_scene("builtin")
+    W, H = 200, 117                                # 15 blocks, the last one 5 rows
+    cam = rt.prepare_camera(sc, W, H, 2, 5)
+    ctx = rt.Context(queue_cap=1 << 20)
+    ctx.upload(sc)
+    full_a, full_r, st_full = render_dev(torch, ctx, cam)
+    for nph in (1, 2, 4):
+        nblocks = (H + 7) // 8
+        kmax = (nblocks + nph - 1) // nph
+        parts_a, parts_r, rays = [], [], 0
+        for ph in range(nph):
+            la = torch.zeros((kmax * 8, W), dtype=torch.int32, device="cuda")
+            lr = torch.zeros((kmax * 8, W, 3), dtype=torch.float32, device="cuda")
+            ctx.render_interleaved(cam, la.data_ptr(), lr.data_ptr(), ph, nph)
+            rays += rays_of(ctx.finish())
+            parts_a.append(la)
+            parts_r.append(lr)
+        ga = torch.stack(parts_a).view(nph, kmax, 8, W).permute(1, 0, 2, 3).reshape(-1, W)[:H]
+        gr = torch.stack(parts_r).view(nph, kmax, 8, W, 3).permute(1, 0, 2, 3, 4).reshape(-1, W, 3)[:H]
+        assert np.array_equal(ga.cpu().numpy().view(np.uint32), full_a)
+        assert np.array_equal(gr.cpu().numpy().view(np.uint32), full_r.view(np.uint32))
+        assert rays == rays_of(st_full)
+    ctx.close()
 
 
 def test_runs_are_deterministic(torch_cuda, make_scene):
