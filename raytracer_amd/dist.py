@@ -1,0 +1,77 @@
+"""Multi-GPU row partition of a frame and the gather of its slices (one process per GPU,
+torch.distributed: backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU tests).
+
+The reference's only parallel build splits the image pixel-cyclically over its workers and has the
+host collect the pixels (ppu/ppu_raytrace.c:237-263, 312-338).  Here the unit is an 8-row block
+(the height of a wave's pixel tile): block b belongs to rank b % world, which balances sky rows
+against sphere rows, and each rank renders its blocks into a compact local buffer
+(rt_hip_render_interleaved).  One all-gather of the equally sized local buffers plus one
+de-interleave copy rebuilds the frame on every rank.  Rendering needs no communication at all.
+"""
+from dataclasses import dataclass
+
+import torch
+
+BLOCK_ROWS = 8
+
+
+@dataclass(frozen=True)
+class RowPlan:
+    height: int
+    world: int
+
+    @property
+    def nblocks(self):
+        return (self.height + BLOCK_ROWS - 1) // BLOCK_ROWS
+
+    @property
+    def blocks_per_rank(self):
+        """Block slots in every rank's local buffer (ranks short of one block leave the last unused)."""
+        return (self.nblocks + self.world - 1) // self.world
+
+    @property
+    def local_rows(self):
+        return self.blocks_per_rank * BLOCK_ROWS
+
+    def blocks_of(self, rank):
+        return list(range(rank, self.nblocks, self.world))
+
+    def rows_of(self, rank):
+        """[(first frame row, row count, first local row)] of the blocks rank renders."""
+        out = []
+        for k, b in enumerate(self.blocks_of(rank)):
+            y = b * BLOCK_ROWS
+            out.append((y, min(BLOCK_ROWS, self.height - y), k * BLOCK_ROWS))
+        return out
+
+
+def deinterleave(gathered, plan, out=None):
+    """gathered: [world * local_rows, ...] = the ranks' local buffers stacked in rank order.
+    Returns the frame [height, ...]: frame block k*world + r = rank r's local block k."""
+    rest = tuple(gathered.shape[1:])
+    g = gathered.view(plan.world, plan.blocks_per_rank, BLOCK_ROWS, *rest)
+    perm = (1, 0, 2) + tuple(range(3, 3 + len(rest)))
+    frame = g.permute(*perm).reshape(plan.world * plan.local_rows, *rest)[:plan.height]
+    if out is None:
+        return frame.contiguous()
+    out.copy_(frame)
+    return out
+
+
+class FrameGather:
+    """Pre-allocated buffers for `all-gather the local slices, de-interleave into the frame`."""
+
+    def __init__(self, plan, width, dtype, device, trailing=()):
+        self.plan = plan
+        shape_tail = (width,) + tuple(trailing)
+        self.local = torch.zeros((plan.local_rows,) + shape_tail, dtype=dtype, device=device)
+        self.gathered = torch.zeros((plan.world * plan.local_rows,) + shape_tail, dtype=dtype, device=device)
+        self.frame = torch.zeros((plan.height,) + shape_tail, dtype=dtype, device=device)
+
+    def gather(self, group=None):
+        import torch.distributed as dist
+        if self.plan.world == 1:
+            self.gathered.copy_(self.local)
+        else:
+            dist.all_gather_into_tensor(self.gathered.view(-1), self.local.view(-1), group=group)
+        return deinterleave(self.gathered, self.plan, out=self.frame)
