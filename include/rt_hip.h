@@ -136,6 +136,9 @@ typedef struct {
     uint64_t polygon_tests, polygon_rej_parallel, polygon_rej_behind, polygon_full, polygon_hits;
     uint64_t lights_lit;        /* (node, light) pairs that passed shadow + facing tests */
     uint64_t nodes_sphere, nodes_polygon;
+    /* polygon inside tests the cheap screening pass could not decide (they took the exact
+     * path), and screening verdicts that contradict the exact test - must be 0 */
+    uint64_t polygon_screen_unsure, polygon_screen_mismatch;
     /* the same, restricted to the fused primary kernel (the dominant kernel):            */
     uint64_t k0_sphere_tests, k0_sphere_hits;
     uint64_t k0_polygon_tests, k0_polygon_rej_parallel, k0_polygon_rej_behind, k0_polygon_full;

@@ -92,6 +92,7 @@ _STAT_U64 = [
 _STAT_U64_B = [
     "sphere_tests", "sphere_hits", "polygon_tests", "polygon_rej_parallel", "polygon_rej_behind",
     "polygon_full", "polygon_hits", "lights_lit", "nodes_sphere", "nodes_polygon",
+    "polygon_screen_unsure", "polygon_screen_mismatch",
     "k0_sphere_tests", "k0_sphere_hits", "k0_polygon_tests", "k0_polygon_rej_parallel",
     "k0_polygon_rej_behind", "k0_polygon_full", "k0_shade_nodes", "k0_nodes_sphere",
     "k0_nodes_polygon", "k0_lights_lit", "k0_shadow_rays", "k0_reflection_rays",

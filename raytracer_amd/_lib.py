@@ -7,7 +7,7 @@ import os
 from . import _abi as A
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "librt_hip.so")  # override: development A/B builds
 
 # every symbol include/rt_hip.h declares
 EXPORTS = [

@@ -234,6 +234,8 @@ void accumulate(rt_hip_stats &s, const uint32_t *cnt, uint32_t levels)
     s.lights_lit += st[ST_LIT];
     s.nodes_sphere += st[ST_NODES_SPH];
     s.nodes_polygon += st[ST_NODES_POLY];
+    s.polygon_screen_unsure += st[ST_POLY_SCREEN_UNSURE];
+    s.polygon_screen_mismatch += st[ST_POLY_SCREEN_MISMATCH];
     s.k0_sphere_tests += st[ST_K0_SPH_TESTS];
     s.k0_sphere_hits += st[ST_K0_SPH_HITS];
     s.k0_polygon_tests += st[ST_K0_POLY_TESTS];

@@ -112,6 +112,7 @@ enum {
     ST_LIT, ST_NODES_SPH, ST_NODES_POLY,
     ST_K0_SPH_TESTS, ST_K0_SPH_HITS, ST_K0_POLY_TESTS, ST_K0_POLY_PAR, ST_K0_POLY_BEHIND,
     ST_K0_POLY_FULL, ST_K0_LIT, ST_K0_NODES_SPH, ST_K0_NODES_POLY,
+    ST_POLY_SCREEN_MISMATCH, ST_POLY_SCREEN_UNSURE,
     ST_COUNT
 };
 static_assert(2 * ST_COUNT <= CNT_STATS_STRIDE, "statistics do not fit their line");

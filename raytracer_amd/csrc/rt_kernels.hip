@@ -29,6 +29,10 @@
 
 #include <math.h>
 
+#ifndef RT_WPE
+#define RT_WPE 1 /* min waves per SIMD asked of the register allocator (launch_bounds 2nd arg) */
+#endif
+
 namespace {
 
 struct Ray {
@@ -49,10 +53,13 @@ template <> struct Tally<false> {
     __device__ __forceinline__ void poly_hit() {}
     __device__ __forceinline__ void lit() {}
     __device__ __forceinline__ void node(bool) {}
+    __device__ __forceinline__ void screen_mismatch() {}
+    __device__ __forceinline__ void screen_unsure() {}
 };
 template <> struct Tally<true> {
     uint32_t n_sph_test = 0, n_sph_hit = 0, n_poly_test = 0, n_poly_par = 0, n_poly_behind = 0,
-             n_poly_full = 0, n_poly_hit = 0, n_lit = 0, n_node_sph = 0, n_node_poly = 0;
+             n_poly_full = 0, n_poly_hit = 0, n_lit = 0, n_node_sph = 0, n_node_poly = 0, n_mismatch = 0,
+             n_unsure = 0;
     __device__ __forceinline__ void sph_test() { ++n_sph_test; }
     __device__ __forceinline__ void sph_hit() { ++n_sph_hit; }
     __device__ __forceinline__ void poly_test() { ++n_poly_test; }
@@ -62,6 +69,8 @@ template <> struct Tally<true> {
     __device__ __forceinline__ void poly_hit() { ++n_poly_hit; }
     __device__ __forceinline__ void lit() { ++n_lit; }
     __device__ __forceinline__ void node(bool sphere) { if (sphere) ++n_node_sph; else ++n_node_poly; }
+    __device__ __forceinline__ void screen_mismatch() { ++n_mismatch; }
+    __device__ __forceinline__ void screen_unsure() { ++n_unsure; }
 };
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
@@ -149,16 +158,230 @@ __device__ __forceinline__ T polygon_angle_sum(const float4 *vtx, uint32_t nv, f
     return total;
 }
 
-__device__ __forceinline__ bool polygon_inside(const float4 *vtx, uint32_t nv, float px, float py,
-                                               float pz)
+/*
+ * Exact-path tie-break.  When the float angle sum lands within 1e-4 of T = 2*pi - .001, the
+ * reference's verdict hinges on its double-precision sum S = sum_i acos(c_i).  Instead of four
+ * double acos calls (95 instructions and ~30 registers each) the sign of S - T is read off the
+ * rotation e^{i(S-T)} = e^{-iT} * prod_i (c_i + i*sqrt(1 - c_i^2)): |S - T| < 2e-4 here, so
+ * sign(S - T) = sign(Im), all in double multiply-adds and square roots (relative error ~1e-15,
+ * the same as the reference's own rounding noise; the two can differ only if |S - T| < ~1e-14,
+ * which needs a sample placed to 1e-14 on the acceptance contour).  A cosine outside [-1,1]
+ * gives NaN and "outside", as acos does in the reference.
+ */
+struct Rot {
+    double re, im;
+};
+__device__ __forceinline__ Rot rot_start()
+{
+    /* e^{-iT}, T = 2*pi - .001:  cos(T) = cos(.001), sin(T) = -sin(.001) */
+    Rot r;
+    r.re = 0.99999950000004166667;
+    r.im = 0.00099999983333334167;
+    return r;
+}
+__device__ __forceinline__ void rot_by_cos(Rot &z, float c)
+{
+    const double cd = (double)c;
+    const double sd = sqrt(1.0 - cd * cd);
+    const double re = z.re * cd - z.im * sd;
+    const double im = z.re * sd + z.im * cd;
+    z.re = re;
+    z.im = im;
+}
+
+/* acos(x) for |x| <= 1 by Abramowitz & Stegun 4.4.46 (|error| <= 2e-8 before float rounding):
+ * acos(x) = sqrt(1-x) * (a0 + a1 x + ... + a7 x^7) for x >= 0, pi - acos(-x) otherwise.  The
+ * square root is the 1-ulp hardware approximation.  Used only by the screening pass below. */
+__device__ __forceinline__ float acos_screen(float x)
+{
+    const float ax = fabsf(x);
+    float p = -0.0012624911f;
+    p = __builtin_fmaf(p, ax, 0.0066700901f);
+    p = __builtin_fmaf(p, ax, -0.0170881256f);
+    p = __builtin_fmaf(p, ax, 0.0308918810f);
+    p = __builtin_fmaf(p, ax, -0.0501743046f);
+    p = __builtin_fmaf(p, ax, 0.0889789874f);
+    p = __builtin_fmaf(p, ax, -0.2145988016f);
+    p = __builtin_fmaf(p, ax, 1.5707963050f);
+    const float r = __builtin_amdgcn_sqrtf(1.0f - ax) * p;
+    return x < 0.0f ? 3.14159265358979f - r : r;
+}
+
+/*
+ * Inside test of ray_intersect_polygon (ray.c:128-176): accept iff
+ *     sum_i acos(costheta(v_i - pt, v_{i+1} - pt)) + .001 > 2*pi      (sum in double).
+ *
+ * Screening pass.  The verdict only changes in a micrometre-wide band around the polygon's
+ * acceptance contour, so most points can be classified from a cheap estimate of the sum:
+ * cosines from the hardware reciprocal square root (no IEEE sqrt / divide), angles from
+ * acos_screen.  With every |cosine| <= 0.9985 the estimate S' differs from the reference's sum S by
+ * less than 4e-5 per edge (cosines agree to 1.2e-6, d(acos)/dx <= 18.3 there: 2.2e-5; acos_screen
+ * 1e-6; float summation 1e-6), so for nv <= 12 edges
+ *     S' > T + 5e-4  =>  S > T  (accept)      S' < T - 5e-4  =>  S < T  (reject),   T = 2*pi - .001.
+ * Anything else - a cosine near +-1 (the point is almost collinear with an edge), a sum close to
+ * T, NaNs, polygons with more than 12 vertices - takes the exact path: the reference's own
+ * arithmetic (float cosines via IEEE sqrt and divide, acos, double sum), with float acosf first
+ * and double acos when even that lands within 1e-4 of T.  Decisions are therefore identical to the
+ * reference's; the instrumented build checks it (ST_POLY_SCREEN_MISMATCH must stay 0).
+ */
+__device__ __forceinline__ int polygon_screen(const float4 *vtx, uint32_t nv, float px, float py, float pz)
+{
+    if (nv > 12u)
+        return 0;
+    const float4 v0 = vtx[0];
+    const float a0x = v0.x - px, a0y = v0.y - py, a0z = v0.z - pz;
+    const float r0 = __builtin_amdgcn_rsqf((a0x * a0x + a0y * a0y) + a0z * a0z);
+    float ax = a0x, ay = a0y, az = a0z, ra = r0;
+    float total = 0.0f, cmax = 0.0f;
+    for (uint32_t i = 1; i < nv; ++i) {
+        const float4 v = vtx[i];
+        const float bx = v.x - px, by = v.y - py, bz = v.z - pz;
+        const float rb = __builtin_amdgcn_rsqf((bx * bx + by * by) + bz * bz);
+        const float c = (dot3(ax, ay, az, bx, by, bz) * ra) * rb;
+        cmax = fmaxf(cmax, fabsf(c));
+        total += acos_screen(c);
+        ax = bx; ay = by; az = bz; ra = rb;
+    }
+    const float c = (dot3(ax, ay, az, a0x, a0y, a0z) * ra) * r0;
+    cmax = fmaxf(cmax, fabsf(c));
+    total += acos_screen(c);
+    const float T = 6.2831853071795864769f - 0.001f;
+    if (!(cmax <= 0.9985f)) /* also catches NaN cosines (fmaxf would drop them: tested below) */
+        return 0;
+    if (total > T + 5e-4f)
+        return 1;
+    if (total < T - 5e-4f)
+        return -1;
+    return 0; /* NaN totals land here too */
+}
+
+__device__ __forceinline__ bool polygon_inside_exact(const float4 *vtx, uint32_t nv, float px, float py,
+                                                     float pz)
 {
     const float twopi = 6.2831853071795864769f;
     const float sf = polygon_angle_sum<float>(vtx, nv, px, py, pz);
     const float margin = (sf + 0.001f) - twopi;
-    if (fabsf(margin) > 1e-4f) /* NaN (a cosine outside [-1,1]) falls through to the exact path */
+    if (fabsf(margin) > 1e-4f) /* NaN (a cosine outside [-1,1]) falls through to the double path */
         return margin > 0.0f;
-    const double sd = polygon_angle_sum<double>(vtx, nv, px, py, pz);
-    return (sd + .001) > (2.0 * 3.14159265358979323846);
+    /* The same float cosines again, folded into the rotation.  Both edge vectors are rebuilt per
+     * edge (same expressions, same values) so that nothing but the rotation lives across the
+     * double-precision square root: this path runs for a few samples per frame, but its register
+     * peak would otherwise set the occupancy of the whole kernel. */
+    Rot z = rot_start();
+#pragma unroll 1
+    for (uint32_t i = 0; i < nv; ++i) {
+        const float4 va = vtx[i];
+        const float4 vb = vtx[(i + 1u == nv) ? 0u : i + 1u];
+        const float ax = va.x - px, ay = va.y - py, az = va.z - pz;
+        const float bx = vb.x - px, by = vb.y - py, bz = vb.z - pz;
+        rot_by_cos(z, dot3(ax, ay, az, bx, by, bz) / (mag3(ax, ay, az) * mag3(bx, by, bz)));
+    }
+    return z.im > 0.0;
+}
+
+/* ---- quads: the four vertices are fetched up front and the four edges are evaluated side by
+ * side, so that the sqrt / divide / acos chains of the edges overlap instead of running as one
+ * dependent chain behind an LDS read per vertex.  Same operations and, for the exact sum, the
+ * same order of additions as the generic loops above (edges 01, 12, 23, 30). ---- */
+struct Quad {
+    float ax[4], ay[4], az[4];
+};
+
+__device__ __forceinline__ Quad quad_edges(const float4 *vtx, float px, float py, float pz)
+{
+    const float4 v0 = vtx[0], v1 = vtx[1], v2 = vtx[2], v3 = vtx[3];
+    Quad q;
+    q.ax[0] = v0.x - px; q.ay[0] = v0.y - py; q.az[0] = v0.z - pz;
+    q.ax[1] = v1.x - px; q.ay[1] = v1.y - py; q.az[1] = v1.z - pz;
+    q.ax[2] = v2.x - px; q.ay[2] = v2.y - py; q.az[2] = v2.z - pz;
+    q.ax[3] = v3.x - px; q.ay[3] = v3.y - py; q.az[3] = v3.z - pz;
+    return q;
+}
+
+__device__ __forceinline__ int quad_screen(const Quad &q)
+{
+    float r[4], c[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        r[i] = __builtin_amdgcn_rsqf((q.ax[i] * q.ax[i] + q.ay[i] * q.ay[i]) + q.az[i] * q.az[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = (i + 1) & 3;
+        c[i] = (dot3(q.ax[i], q.ay[i], q.az[i], q.ax[j], q.ay[j], q.az[j]) * r[i]) * r[j];
+    }
+    const float cmax = fmaxf(fmaxf(fabsf(c[0]), fabsf(c[1])), fmaxf(fabsf(c[2]), fabsf(c[3])));
+    const float total = (acos_screen(c[0]) + acos_screen(c[1])) + (acos_screen(c[2]) + acos_screen(c[3]));
+    const float T = 6.2831853071795864769f - 0.001f;
+    if (!(cmax <= 0.9985f))
+        return 0;
+    if (total > T + 5e-4f)
+        return 1;
+    if (total < T - 5e-4f)
+        return -1;
+    return 0; /* NaN cosines make the total NaN and land here */
+}
+
+__device__ __forceinline__ bool quad_inside_exact(const Quad &q)
+{
+    float m[4], c[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        m[i] = mag3(q.ax[i], q.ay[i], q.az[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = (i + 1) & 3;
+        c[i] = dot3(q.ax[i], q.ay[i], q.az[i], q.ax[j], q.ay[j], q.az[j]) / (m[i] * m[j]);
+    }
+    const float twopi = 6.2831853071795864769f;
+    const float sf = ((acosf(c[0]) + acosf(c[1])) + acosf(c[2])) + acosf(c[3]);
+    const float margin = (sf + 0.001f) - twopi;
+    if (fabsf(margin) > 1e-4f)
+        return margin > 0.0f;
+    Rot z = rot_start();
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i)
+        rot_by_cos(z, c[i]);
+    return z.im > 0.0;
+}
+
+/* QUAD: use the side-by-side quad evaluation (more registers, less latency).  The closest-hit
+ * searches use it; the any-hit shadow search, which runs with all the shading state live, keeps
+ * the register-light loops so that the kernel's register peak (and with it the number of waves a
+ * SIMD can hold) is not set by a path that rarely runs. */
+template <bool STATS, bool QUAD>
+__device__ __forceinline__ bool polygon_inside(const float4 *vtx, uint32_t nv, float px, float py,
+                                               float pz, Tally<STATS> &tl)
+{
+#ifdef RT_ABL_NO_ANGLESUM /* development ablation: price of the angle sum (wrong pixels) */
+    return px > -15.0f && px < 7.0f && pz > -100.0f && pz < 0.0f;
+#endif
+    if (QUAD && nv == 4u) {
+        const Quad q = quad_edges(vtx, px, py, pz);
+        const int s = quad_screen(q);
+        if constexpr (STATS) { /* instrumented build: always run the exact test and compare */
+            const bool e = quad_inside_exact(q);
+            if (s != 0 && (s > 0) != e)
+                tl.screen_mismatch();
+            if (s == 0)
+                tl.screen_unsure();
+            return e;
+        }
+        if (s != 0)
+            return s > 0;
+        return quad_inside_exact(q);
+    }
+    const int s = polygon_screen(vtx, nv, px, py, pz);
+    if constexpr (STATS) {
+        const bool e = polygon_inside_exact(vtx, nv, px, py, pz);
+        if (s != 0 && (s > 0) != e)
+            tl.screen_mismatch();
+        if (s == 0)
+            tl.screen_unsure();
+        return e;
+    }
+    if (s != 0)
+        return s > 0;
+    return polygon_inside_exact(vtx, nv, px, py, pz);
 }
 
 /* powf(s, ke) of raytrace.c:371.  glibc's powf evaluates in double and is correctly rounded in
@@ -293,8 +516,8 @@ __device__ __forceinline__ void intersect_all(const DevScene &S, const float4 *l
             if (!wins && !STATS)
                 continue;
             const float px = r.ox + r.dx * w, py = r.oy + r.dy * w, pz = r.oz + r.dz * w;
-            const bool inside = polygon_inside(lds_poly + 2 * S.nPoly + __float_as_uint(info.x),
-                                               __float_as_uint(info.y), px, py, pz);
+            const bool inside = polygon_inside<STATS, !ANYHIT>(lds_poly + 2 * S.nPoly + __float_as_uint(info.x),
+                                                      __float_as_uint(info.y), px, py, pz, tl);
             if (inside) {
                 tl.poly_hit();
                 if (wins) {
@@ -374,9 +597,16 @@ __device__ __forceinline__ void wave_reserve(unsigned long long *line, bool want
 
 __device__ __forceinline__ float clamp1(float v) { return v > 1.0f ? 1.0f : v; } /* color.c:44-54 */
 
+/* wave totals (ballot popcounts: they live in scalar registers, not one VGPR per lane) */
 struct SpawnCounts {
     uint32_t shade_nodes = 0, refl = 0, trans = 0;
 };
+__device__ __forceinline__ uint32_t wave_count(bool p) { return (uint32_t)__popcll(__ballot(p)); }
+__device__ __forceinline__ void wave_add_total(uint64_t *stats, int slot, uint32_t total)
+{
+    if (lane_id() == 0 && total != 0)
+        atomicAdd((unsigned long long *)&stats[slot], (unsigned long long)total);
+}
 
 /*
  * get_shade_color_phong (raytrace.c:282-564) for one hit, minus the recursion: computes the
@@ -384,19 +614,24 @@ struct SpawnCounts {
  * either returns a finished leaf colour or allocates a tree node and queues the reflection /
  * transmission rays for the next level.
  *
- * eye          : the ray that found the hit (pushed origin, possibly unnormalised direction)
- * hit, obj, d  : whether this lane has a hit, which object, at what ray parameter
+ * eye_src      : gives back the origin / direction of the ray that found the hit (pushed
+ *                origin, possibly unnormalised direction) when they are needed again after the
+ *                shadow rays: re-read from the queue or rebuilt from the sample position, so
+ *                that they do not occupy registers during the any-hit searches
+ * hit, obj     : whether this lane has a hit and which object
+ * px,py,pz     : the hit point, origin + direction * distance (ray.c:121-122, 236-237)
  * level        : recursion depth of this node
  * link         : value stored in the node's link word (parent<<3|slot for level >= 1,
  *                next-root<<3 for level 0); flags are OR-ed in here
  * Returns true when the lane produced a tree node (index in node_idx); otherwise `leaf` holds
  * the clamped colour of a childless node.
  */
-template <bool TILED, bool STATS>
+template <bool TILED, bool STATS, typename EyeSource>
 __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCamera &C,
                                                 const DevWork &Wk, const float4 *lds_poly,
-                                                float4 *lds_sph, bool hit, const Ray &eye,
-                                                uint32_t obj, float d, uint32_t level,
+                                                float4 *lds_sph, uint32_t *lds_vis, bool hit,
+                                                const EyeSource &eye_src, float px, float py, float pz,
+                                                uint32_t obj, uint32_t level,
                                                 uint32_t link, uint32_t shard, uint32_t node_base,
                                                 uint32_t node_room, float leaf[3], uint32_t &node_idx,
                                                 SpawnCounts &sc, Tally<STATS> &tl)
@@ -405,26 +640,112 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     if (!TILED && !hit)
         return false;
 
-    float4 mA, mB, mC, mD, gE;
+    /*
+     * Two passes over the lights, so that the any-hit searches (the register-hungry part: sphere
+     * roots in double, polygon angle sums) run while only the hit point and the exclusion ids are
+     * live, and the material / normal / view vector are loaded and built only afterwards:
+     *   pass A  shadow rays of all lights -> visibility bits
+     *   pass B  Phong terms of the visible lights, in light order (the sums are order-sensitive)
+     * The shadow direction is rebuilt in pass B by the same expressions, hence bit-identical.
+     */
+    uint32_t exc_sph = RT_NONE, exc_poly = RT_NONE;
     if (hit) {
-        mA = S.objA[obj];
-        mB = S.objB[obj];
-        mC = S.objC[obj];
-        mD = S.objD[obj];
-        gE = S.objE[obj];
-        sc.shade_nodes++;
-    } else {
-        mA = mB = mC = mD = gE = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 g = S.objD[obj];
+        const bool sph = __float_as_uint(g.y) == 1u; /* GEOMETRY_SPHERE */
+        exc_sph = sph ? __float_as_uint(g.z) : RT_NONE;
+        exc_poly = sph ? RT_NONE : __float_as_uint(g.z);
+        tl.node(sph);
     }
-    const bool is_sphere = __float_as_uint(mD.y) == 1u; /* GEOMETRY_SPHERE */
-    if (hit)
-        tl.node(is_sphere);
-    const uint32_t glist = __float_as_uint(mD.z);
-    const uint32_t exc_sph = is_sphere ? glist : RT_NONE;
-    const uint32_t exc_poly = is_sphere ? RT_NONE : glist;
+    sc.shade_nodes += wave_count(hit);
 
-    /* intersection point: origin + direction * distance (ray.c:121-122, 236-237) */
-    const float px = eye.ox + eye.dx * d, py = eye.oy + eye.dy * d, pz = eye.oz + eye.dz * d;
+    float dfr = 0.f, dfg = 0.f, dfb = 0.f, spr = 0.f, spg = 0.f, spb = 0.f;
+#ifdef RT_ABL_NO_LIGHTS /* development ablation: price of shadow rays + Phong (wrong pixels) */
+    const uint32_t n_lights = 0;
+#else
+    const uint32_t n_lights = S.nLights;
+#endif
+    /* pass A (raytrace.c:327-347).  Visibility words of all but the last 32 lights go to LDS. */
+    uint32_t visible = 0;
+    for (uint32_t l = 0; l < n_lights; ++l) {
+        const float4 lp = S.light_pos[l];
+        /* ray_create(pt, light) ray.c:29-41 */
+        Ray sh;
+        sh.ox = px; sh.oy = py; sh.oz = pz;
+        sh.dx = lp.x - px; sh.dy = lp.y - py; sh.dz = lp.z - pz;
+        sh.mag = mag3(sh.dx, sh.dy, sh.dz);
+        const float inv = 1.0f / sh.mag;
+        sh.dx = sh.dx * inv; sh.dy = sh.dy * inv; sh.dz = sh.dz * inv;
+        tinypush(sh);
+        float sd;
+        uint32_t sobj;
+        intersect_all<TILED, true, true, STATS>(S, lds_poly, lds_sph, hit, sh, exc_sph, exc_poly, sd,
+                                                sobj, tl);
+        if (hit && sobj == RT_NONE)
+            visible |= 1u << (l & 31u);
+        if ((l & 31u) == 31u && l + 1u < n_lights) {
+            lds_vis[(l >> 5) * RT_BLOCK + threadIdx.x] = visible; /* own slot: no barrier needed */
+            visible = 0;
+        }
+    }
+    /* the eye ray's origin, back from where it is kept (cannot be merged with the first read) */
+    float eox, eoy, eoz;
+    eye_src.origin(eox, eoy, eoz);
+
+    /* pass B (raytrace.c:349-384) */
+    if (hit && n_lights != 0) {
+        const float4 gD = S.objD[obj];
+        const float4 gE = S.objE[obj];
+        const float ke = S.objC[obj].y;
+        /* normal: geometry.c:37-57 */
+        float Nx, Ny, Nz;
+        if (__float_as_uint(gD.y) == 1u) {
+            const float nx = px - gE.x, ny = py - gE.y, nz = pz - gE.z;
+            const float m = mag3(nx, ny, nz);
+            Nx = nx / m; Ny = ny / m; Nz = nz / m;
+        } else {
+            Nx = gE.x; Ny = gE.y; Nz = gE.z;
+        }
+        /* V = normalize(eye.origin - pt) raytrace.c:318-320 */
+        float Vx = eox - px, Vy = eoy - py, Vz = eoz - pz;
+        {
+            const float m = mag3(Vx, Vy, Vz);
+            Vx = Vx / m; Vy = Vy / m; Vz = Vz / m;
+        }
+        const uint32_t last = (n_lights - 1u) >> 5;
+        for (uint32_t c = 0; c <= last; ++c) {
+            uint32_t m = (c == last) ? visible : lds_vis[c * RT_BLOCK + threadIdx.x];
+            while (m) {
+                const uint32_t l = c * 32u + (uint32_t)__ffs((int)m) - 1u;
+                m &= m - 1u;
+                const float4 lp = S.light_pos[l];
+                const float4 lc = S.light_col[l];
+                float sx = lp.x - px, sy = lp.y - py, sz = lp.z - pz;
+                const float inv = 1.0f / mag3(sx, sy, sz);
+                sx = sx * inv; sy = sy * inv; sz = sz * inv;
+                const float t = dot3(sx, sy, sz, Nx, Ny, Nz);
+                if (!(t <= 0.0f)) {
+                    tl.lit();
+                    const float t2 = 2.0f * t;
+                    const float Rx = Nx * t2 - sx, Ry = Ny * t2 - sy, Rz = Nz * t2 - sz;
+                    dfr += lc.x * t; dfg += lc.y * t; dfb += lc.z * t;
+                    float s = dot3(Rx, Ry, Rz, Vx, Vy, Vz);
+                    if (s < 0.0f)
+                        s = 0.0f;
+                    s = phong_pow(s, ke);
+                    spr += lc.x * s; spg += lc.y * s; spb += lc.z * s;
+                }
+            }
+        }
+    }
+    if (!hit)
+        return false;
+
+    /* material, object colour, normal and view vector for the combine and the spawn */
+    const float4 mA = S.objA[obj];
+    const float4 mB = S.objB[obj];
+    const float4 mC = S.objC[obj];
+    const float4 mD = S.objD[obj];
+    const bool is_sphere = __float_as_uint(mD.y) == 1u;
 
     /* get_object_color object3d.c:64-117 */
     float ocr, ocg, ocb;
@@ -443,56 +764,6 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     float outg = (ocg * S.ambient[1]) * mA.w;
     float outb = (ocb * S.ambient[2]) * mA.w;
 
-    /* normal: geometry.c:37-57 */
-    float Nx, Ny, Nz;
-    if (is_sphere) {
-        const float nx = px - gE.x, ny = py - gE.y, nz = pz - gE.z;
-        const float m = mag3(nx, ny, nz);
-        Nx = nx / m; Ny = ny / m; Nz = nz / m;
-    } else {
-        Nx = gE.x; Ny = gE.y; Nz = gE.z;
-    }
-    /* V = normalize(eye.origin - pt) raytrace.c:318-320 */
-    float Vx = eye.ox - px, Vy = eye.oy - py, Vz = eye.oz - pz;
-    {
-        const float m = mag3(Vx, Vy, Vz);
-        Vx = Vx / m; Vy = Vy / m; Vz = Vz / m;
-    }
-
-    float dfr = 0.f, dfg = 0.f, dfb = 0.f, spr = 0.f, spg = 0.f, spb = 0.f;
-    for (uint32_t l = 0; l < S.nLights; ++l) { /* raytrace.c:327-384 */
-        const float4 lp = S.light_pos[l];
-        const float4 lc = S.light_col[l];
-        /* ray_create(pt, light) ray.c:29-41 */
-        Ray sh;
-        sh.ox = px; sh.oy = py; sh.oz = pz;
-        sh.dx = lp.x - px; sh.dy = lp.y - py; sh.dz = lp.z - pz;
-        sh.mag = mag3(sh.dx, sh.dy, sh.dz);
-        const float inv = 1.0f / sh.mag;
-        sh.dx = sh.dx * inv; sh.dy = sh.dy * inv; sh.dz = sh.dz * inv;
-        tinypush(sh);
-        float sd;
-        uint32_t sobj;
-        intersect_all<TILED, true, true, STATS>(S, lds_poly, lds_sph, hit, sh, exc_sph, exc_poly, sd,
-                                                sobj, tl);
-        if (hit && sobj == RT_NONE) {
-            const float t = dot3(sh.dx, sh.dy, sh.dz, Nx, Ny, Nz);
-            if (!(t <= 0.0f)) {
-                tl.lit();
-                const float t2 = 2.0f * t;
-                const float Rx = Nx * t2 - sh.dx, Ry = Ny * t2 - sh.dy, Rz = Nz * t2 - sh.dz;
-                dfr += lc.x * t; dfg += lc.y * t; dfb += lc.z * t;
-                float s = dot3(Rx, Ry, Rz, Vx, Vy, Vz);
-                if (s < 0.0f)
-                    s = 0.0f;
-                s = phong_pow(s, mC.y);
-                spr += lc.x * s; spg += lc.y * s; spb += lc.z * s;
-            }
-        }
-    }
-    if (!hit)
-        return false;
-
     /* raytrace.c:390-401 */
     outr += (mC.x * dfr) * ocr + (mB.w * spr) * mB.x;
     outg += (mC.x * dfg) * ocg + (mB.w * spg) * mB.y;
@@ -501,11 +772,31 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     const float kr = mC.z, kt = mC.w;
     const bool want_r = (kr != 0.0f) && (level != C.depth); /* raytrace.c:405 */
     const bool want_t = (kt != 0.0f) && (level != C.depth); /* raytrace.c:452 */
+    sc.refl += wave_count(want_r);
+    sc.trans += wave_count(want_t);
     if (!(want_r || want_t)) {
         leaf[0] = clamp1(outr); /* raytrace.c:562 */
         leaf[1] = clamp1(outg);
         leaf[2] = clamp1(outb);
         return false;
+    }
+
+    /* normal (geometry.c:37-57) and V = normalize(eye.origin - pt) (raytrace.c:318-320) again */
+    float Nx, Ny, Nz;
+    {
+        const float4 gE = S.objE[obj];
+        if (is_sphere) {
+            const float nx = px - gE.x, ny = py - gE.y, nz = pz - gE.z;
+            const float m = mag3(nx, ny, nz);
+            Nx = nx / m; Ny = ny / m; Nz = nz / m;
+        } else {
+            Nx = gE.x; Ny = gE.y; Nz = gE.z;
+        }
+    }
+    float Vx = eox - px, Vy = eoy - py, Vz = eoz - pz;
+    {
+        const float m = mag3(Vx, Vy, Vz);
+        Vx = Vx / m; Vy = Vy / m; Vz = Vz / m;
     }
 
     /* tree node + child rays: one reservation per wave */
@@ -535,7 +826,6 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
         rr.dx = Nx * t2 - Vx; rr.dy = Ny * t2 - Vy; rr.dz = Nz * t2 - Vz;
         rr.mag = 9999999.9f;
         tinypush(rr);
-        sc.refl++;
     }
     if (slot_r != RT_NONE) {
         Wk.qA[nq][qbase + slot_r] = make_float4(rr.ox, rr.oy, rr.oz, rr.mag);
@@ -545,7 +835,9 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     Ray tr;
     if (want_t) {
         float nit = 1.0f / mD.x;
-        const float Tx = eye.dx * nit, Ty = eye.dy * nit, Tz = eye.dz * nit;
+        float edx, edy, edz;
+        eye_src.direction(edx, edy, edz);
+        const float Tx = edx * nit, Ty = edy * nit, Tz = edz * nit;
         const float cs = dot3(Vx, Vy, Vz, Nx, Ny, Nz);
         float Fx = Nx, Fy = Ny, Fz = Nz;
         if (cs < 0.0f) { /* inside the object moving out */
@@ -564,7 +856,6 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
             tr.mag = 99999.9f;
         }
         tinypush(tr);
-        sc.trans++;
     }
     if (slot_t != RT_NONE) {
         Wk.qA[nq][qbase + slot_t] = make_float4(tr.ox, tr.oy, tr.oz, tr.mag);
@@ -572,6 +863,62 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     }
     return true;
 }
+
+/* get_pixel_color's ray of sub-sample (i,j) (raytrace.c:751-771): shift = N*vd + U*fu + V*fv;
+ * target = eye + shift; ray_create(eye, target) */
+__device__ __forceinline__ void primary_ray(const DevCamera &C, float fu0, float fv0, uint32_t i,
+                                            uint32_t j, Ray &r)
+{
+    const float fv = fv0 + (C.sppHalf + (float)j * C.sppW);
+    const float fu = fu0 + (C.sppHalf + (float)i * C.sppW);
+    const float sx = (C.shiftN[0] + C.U[0] * fu) + C.V[0] * fv;
+    const float sy = (C.shiftN[1] + C.U[1] * fu) + C.V[1] * fv;
+    const float sz = (C.shiftN[2] + C.U[2] * fu) + C.V[2] * fv;
+    const float tx = C.eye[0] + sx, ty = C.eye[1] + sy, tz = C.eye[2] + sz;
+    r.ox = C.eye[0]; r.oy = C.eye[1]; r.oz = C.eye[2];
+    r.dx = tx - r.ox; r.dy = ty - r.oy; r.dz = tz - r.oz;
+    r.mag = mag3(r.dx, r.dy, r.dz);
+    const float inv = 1.0f / r.mag;
+    r.dx = r.dx * inv; r.dy = r.dy * inv; r.dz = r.dz * inv;
+}
+
+/* Where shade_and_spawn gets the eye ray back from after the shadow rays (see there).  The empty
+ * asm makes the input opaque, so the compiler cannot fold the rebuild / re-read into the first
+ * one and keep the values in registers across the any-hit searches after all. */
+struct PrimaryEye {
+    const DevCamera &C;
+    float fu0, fv0;
+    uint32_t i, j;
+    __device__ __forceinline__ void origin(float &x, float &y, float &z) const
+    {
+        x = C.eye[0]; y = C.eye[1]; z = C.eye[2];
+    }
+    __device__ __forceinline__ void direction(float &x, float &y, float &z) const
+    {
+        float f = fu0;
+        asm volatile("" : "+v"(f));
+        Ray r;
+        primary_ray(C, f, fv0, i, j, r);
+        x = r.dx; y = r.dy; z = r.dz;
+    }
+};
+struct QueuedEye {
+    const float4 *qa, *qb; /* this lane's queue entry */
+    __device__ __forceinline__ void origin(float &x, float &y, float &z) const
+    {
+        const float4 *p = qa;
+        asm volatile("" : "+v"(p));
+        const float4 a = *p;
+        x = a.x; y = a.y; z = a.z;
+    }
+    __device__ __forceinline__ void direction(float &x, float &y, float &z) const
+    {
+        const float4 *p = qb;
+        asm volatile("" : "+v"(p));
+        const float4 b = *p;
+        x = b.x; y = b.y; z = b.z;
+    }
+};
 
 template <bool STATS>
 __device__ __forceinline__ void flush_tally(uint64_t *st, Tally<STATS> &tl, bool k0)
@@ -587,6 +934,8 @@ __device__ __forceinline__ void flush_tally(uint64_t *st, Tally<STATS> &tl, bool
         wave_add_stat(st, ST_LIT, tl.n_lit);
         wave_add_stat(st, ST_NODES_SPH, tl.n_node_sph);
         wave_add_stat(st, ST_NODES_POLY, tl.n_node_poly);
+        wave_add_stat(st, ST_POLY_SCREEN_MISMATCH, tl.n_mismatch);
+        wave_add_stat(st, ST_POLY_SCREEN_UNSURE, tl.n_unsure);
         if (k0) {
             wave_add_stat(st, ST_K0_SPH_TESTS, tl.n_sph_test);
             wave_add_stat(st, ST_K0_SPH_HITS, tl.n_sph_hit);
@@ -605,12 +954,13 @@ __device__ __forceinline__ void flush_tally(uint64_t *st, Tally<STATS> &tl, bool
 /* k_primary: get_pixel_color + get_ray_color + depth-0 get_shade_color_phong, fused           */
 /* ------------------------------------------------------------------------------------------ */
 template <bool TILED, bool STATS>
-__global__ __launch_bounds__(RT_BLOCK) void k_primary(DevScene S, DevCamera C, DevWork Wk,
+__global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_primary(DevScene S, DevCamera C, DevWork Wk,
                                                       DevRows R)
 {
     extern __shared__ __attribute__((aligned(16))) float4 lds[];
     float4 *lds_poly = lds;
     float4 *lds_sph = lds + S.nPolySlots;
+    uint32_t *lds_vis = (uint32_t *)(lds_sph + (TILED ? (uint32_t)RT_TILE_SPHERES : S.nSph));
     block_copy(lds_poly, S.poly, S.nPolySlots);
     if (!TILED)
         block_copy(lds_sph, S.sph, S.nSph);
@@ -637,20 +987,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_primary(DevScene S, DevCamera C, D
     Tally<STATS> tl;
 
     for (uint32_t j = 0; j < C.sqrtSpp; ++j) {
-        const float fv = fv0 + (C.sppHalf + (float)j * C.sppW);
         for (uint32_t i = 0; i < C.sqrtSpp; ++i) {
-            const float fu = fu0 + (C.sppHalf + (float)i * C.sppW);
-            /* shift = N*vd + U*fu + V*fv; target = eye + shift; ray_create(eye, target) */
-            const float sx = (C.shiftN[0] + C.U[0] * fu) + C.V[0] * fv;
-            const float sy = (C.shiftN[1] + C.U[1] * fu) + C.V[1] * fv;
-            const float sz = (C.shiftN[2] + C.U[2] * fu) + C.V[2] * fv;
-            const float tx = C.eye[0] + sx, ty = C.eye[1] + sy, tz = C.eye[2] + sz;
             Ray r;
-            r.ox = C.eye[0]; r.oy = C.eye[1]; r.oz = C.eye[2];
-            r.dx = tx - r.ox; r.dy = ty - r.oy; r.dz = tz - r.oz;
-            r.mag = mag3(r.dx, r.dy, r.dz);
-            const float inv = 1.0f / r.mag;
-            r.dx = r.dx * inv; r.dy = r.dy * inv; r.dz = r.dz * inv;
+            primary_ray(C, fu0, fv0, i, j, r);
 
             float d;
             uint32_t obj;
@@ -659,9 +998,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_primary(DevScene S, DevCamera C, D
             const bool hit = valid && (obj != RT_NONE);
             float leaf[3] = {S.bg[0], S.bg[1], S.bg[2]}; /* miss: raytrace.c:700-703 */
             uint32_t node;
-            const bool deferred = shade_and_spawn<TILED, STATS>(S, C, Wk, lds_poly, lds_sph, hit, r, obj, d,
-                                                                0u, head << 3, shard, node_base, Wk.capS, leaf,
-                                                                node, sc, tl);
+            const float px = r.ox + r.dx * d, py = r.oy + r.dy * d, pz = r.oz + r.dz * d;
+            const PrimaryEye eye_src{C, fu0, fv0, i, j};
+            const bool deferred = shade_and_spawn<TILED, STATS>(S, C, Wk, lds_poly, lds_sph, lds_vis, hit,
+                                                                eye_src, px, py, pz, obj, 0u, head << 3, shard,
+                                                                node_base, Wk.capS, leaf, node, sc, tl);
             if (deferred) {
                 head = node; /* resolved later; chain of this pixel's roots */
             } else {
@@ -676,9 +1017,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_primary(DevScene S, DevCamera C, D
             make_float4(accr, accg, accb, __uint_as_float(head));
 
     uint64_t *st = (uint64_t *)(Wk.counters + CNT_STATS + shard * CNT_STATS_STRIDE);
-    wave_add_stat(st, ST_K0_SHADE_NODES, sc.shade_nodes);
-    wave_add_stat(st, ST_K0_REFL, sc.refl);
-    wave_add_stat(st, ST_K0_TRANS, sc.trans);
+    wave_add_total(st, ST_K0_SHADE_NODES, sc.shade_nodes);
+    wave_add_total(st, ST_K0_REFL, sc.refl);
+    wave_add_total(st, ST_K0_TRANS, sc.trans);
     flush_tally<STATS>(st, tl, true);
 }
 
@@ -686,12 +1027,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_primary(DevScene S, DevCamera C, D
 /* k_bounce: one queued secondary ray per lane (reflection / transmission of level-1 nodes)    */
 /* ------------------------------------------------------------------------------------------ */
 template <bool TILED, bool STATS>
-__global__ __launch_bounds__(RT_BLOCK) void k_bounce(DevScene S, DevCamera C, DevWork Wk,
+__global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_bounce(DevScene S, DevCamera C, DevWork Wk,
                                                      uint32_t level)
 {
     extern __shared__ __attribute__((aligned(16))) float4 lds[];
     float4 *lds_poly = lds;
     float4 *lds_sph = lds + S.nPolySlots;
+    uint32_t *lds_vis = (uint32_t *)(lds_sph + (TILED ? (uint32_t)RT_TILE_SPHERES : S.nSph));
 
     /* block b consumes shard b % RT_SHARDS, as slice b / RT_SHARDS of gridDim.x / RT_SHARDS */
     const uint32_t shard = blockIdx.x % RT_SHARDS;
@@ -740,7 +1082,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_bounce(DevScene S, DevCamera C, De
         const bool hit = active && (obj != RT_NONE);
         float leaf[3] = {S.bg[0], S.bg[1], S.bg[2]}; /* miss: kr/kt * bgColor raytrace.c:446,509,553 */
         uint32_t node;
-        const bool deferred = shade_and_spawn<TILED, STATS>(S, C, Wk, lds_poly, lds_sph, hit, r, obj, d, level,
+        const float px = r.ox + r.dx * d, py = r.oy + r.dy * d, pz = r.oz + r.dz * d;
+        const uint32_t qi = qbase + (active ? i : 0u);
+        const QueuedEye eye_src{&Wk.qA[q][qi], &Wk.qB[q][qi]};
+        const bool deferred = shade_and_spawn<TILED, STATS>(S, C, Wk, lds_poly, lds_sph, lds_vis, hit, eye_src,
+                                                            px, py, pz, obj, level,
                                                             ((parent >> 1) << 3) | (parent & 1u), shard, node_base,
                                                             node_room, leaf, node, sc, tl);
         if (active && !deferred && (parent >> 1) < Wk.cap) {
@@ -751,9 +1097,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_bounce(DevScene S, DevCamera C, De
         }
     }
     uint64_t *st = (uint64_t *)(Wk.counters + CNT_STATS + shard * CNT_STATS_STRIDE);
-    wave_add_stat(st, ST_KB_SHADE_NODES, sc.shade_nodes);
-    wave_add_stat(st, ST_KB_REFL, sc.refl);
-    wave_add_stat(st, ST_KB_TRANS, sc.trans);
+    wave_add_total(st, ST_KB_SHADE_NODES, sc.shade_nodes);
+    wave_add_total(st, ST_KB_REFL, sc.refl);
+    wave_add_total(st, ST_KB_TRANS, sc.trans);
     flush_tally<STATS>(st, tl, false);
 }
 
@@ -839,7 +1185,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DevCamera C, DevWork Wk, D
 size_t rt_scene_lds_bytes(const DevScene &S)
 {
     const uint32_t sph = S.nSph < RT_TILE_SPHERES ? S.nSph : RT_TILE_SPHERES;
-    return (size_t)(S.nPolySlots + sph) * sizeof(float4);
+    /* + one visibility word per thread for every full group of 32 lights before the last group */
+    const uint32_t vis_words = S.nLights > 32u ? ((S.nLights - 1u) / 32u) * RT_BLOCK : 0u;
+    return (size_t)(S.nPolySlots + sph) * sizeof(float4) + (size_t)vis_words * sizeof(uint32_t);
 }
 
 void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,

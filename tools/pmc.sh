@@ -11,7 +11,8 @@ seen=set()
 for r in csv.DictReader(open(f)):
     k=r["Kernel_Name"]
     if "k_" not in k: continue
-    k=k.split("(")[0][-40:]
+    import re
+    m=re.search(r"(k_[a-z]+)(<[^>]*>)?", k); k=(m.group(1)+(m.group(2) or "")) if m else k[:40]
     agg[k][r["Counter_Name"]]+=float(r["Counter_Value"])
     seen.add((k,r["Dispatch_Id"]))
 for k,d in seen: calls[k]+=1
