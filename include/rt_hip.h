@@ -229,6 +229,15 @@ void rt_hip_ctx_set_batch_samples(rt_hip_ctx *ctx, uint64_t max_samples);
 const char *rt_hip_last_error(void);
 const char *rt_hip_version(void);
 
+/* Diagnostic (no counterpart in the reference): runs the kernels' correctly rounded divide /
+ * square-root helpers (csrc/rt_arith.h) over n operand triples so a caller can compare them with
+ * IEEE arithmetic on the host - the reference's `/`, sqrt() and vec4_normalize (vector4.c:219-262).
+ * All pointers are DEVICE pointers.  d_out holds 7 floats per element i:
+ *   sqrt(a), a/b with special-operand fix-up, a/b without, normalize(a,b,c).xyz, 1.0f/b
+ * d_out64[i] = sqrt((double)a) by the positive-normal-only helper.  Blocking. */
+int  rt_hip_selftest_arith(const float *d_a, const float *d_b, const float *d_c, uint32_t n,
+                           float *d_out, double *d_out64, void *stream);
+
 /* ---- host-side scene helpers (reference scene.c / geometry.c equivalents) ---------- */
 
 /* poly_plane -- geometry.c:14-34 (normal from the first three vertices, F forced >= 0). */

@@ -15,7 +15,7 @@ EXPORTS = [
     "rt_hip_scene_upload", "rt_hip_render_rows", "rt_hip_render_interleaved", "rt_hip_finish", "rt_hip_render_stats",
     "rt_hip_ctx_set_timing", "rt_hip_ctx_set_batch_samples", "rt_hip_last_error", "rt_hip_version",
     "rt_poly_plane", "rt_scene_builtin", "rt_parse_scene", "rt_scene_free", "rt_scene_synthetic",
-    "rt_write_image",
+    "rt_write_image", "rt_hip_selftest_arith",
 ]
 
 _lib = None
@@ -62,6 +62,8 @@ def load():
     lib.rt_hip_ctx_set_batch_samples.restype = None
     lib.rt_hip_last_error.restype = C.c_char_p
     lib.rt_hip_version.restype = C.c_char_p
+    lib.rt_hip_selftest_arith.argtypes = [vp, vp, vp, u32, vp, vp, vp]
+    lib.rt_hip_selftest_arith.restype = i32
     lib.rt_poly_plane.argtypes = [P(A.rt_plane), P(A.rt_polygon)]
     lib.rt_poly_plane.restype = None
     lib.rt_scene_builtin.argtypes = [P(A.rt_scene_t)]

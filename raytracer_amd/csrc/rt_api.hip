@@ -373,6 +373,19 @@ extern "C" {
 const char *rt_hip_last_error(void) { return g_err; }
 const char *rt_hip_version(void) { return "rt_hip 0.1 (gfx950)"; }
 
+int rt_hip_selftest_arith(const float *d_a, const float *d_b, const float *d_c, uint32_t n, float *d_out,
+                          double *d_out64, void *stream)
+{
+    if (n && (!d_a || !d_b || !d_c || !d_out || !d_out64)) {
+        set_err("null argument");
+        return RT_E_INVALID;
+    }
+    rt_launch_selftest_arith(d_a, d_b, d_c, n, d_out, d_out64, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
 int rt_hip_ctx_create(rt_hip_ctx **out, int device, uint64_t max_queue_rays)
 {
     if (!out) {

@@ -26,6 +26,7 @@
  * exponent is a double square-and-multiply chain (see polygon_inside / phong_pow).
  */
 #include "rt_device.h"
+#include "rt_arith.h"
 
 #include <math.h>
 
@@ -89,7 +90,7 @@ __device__ __forceinline__ void wave_add_stat(uint64_t *stats, int slot, uint32_
 /* vec4_magnitude vector4.c:219-233: (float)sqrt((double)float_sum) == correctly rounded sqrtf */
 __device__ __forceinline__ float mag3(float x, float y, float z)
 {
-    return sqrtf((x * x + y * y) + z * z);
+    return sqrt_rn((x * x + y * y) + z * z);
 }
 
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)
@@ -97,13 +98,28 @@ __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, fl
     return (ax * bx + ay * by) + az * bz; /* vec4_dot vector4.c:141-143, left to right */
 }
 
+/* vec4_normalize vector4.c:240-262: every component DIVIDED by the length (not multiplied by a
+ * reciprocal); the three quotients share one refined reciprocal (rt_arith.h) */
+__device__ __forceinline__ void normalize3(float &x, float &y, float &z)
+{
+    const float m = mag3(x, y, z);
+    const float rm = rcp_refined(m);
+    x = div_with(x, m, rm);
+    y = div_with(y, m, rm);
+    z = div_with(z, m, rm);
+}
+
+/* 1.0f / m as ray_create computes it (ray.c:36-37) */
+__device__ __forceinline__ float recip_rn(float m) { return div_with(1.0f, m, rcp_refined(m)); }
+
 /* ray_tinypush ray.c:72-86: origin += normalize(direction) * 0.001f (normalize divides) */
 __device__ __forceinline__ void tinypush(Ray &r)
 {
-    const float m = mag3(r.dx, r.dy, r.dz);
-    r.ox = r.ox + (r.dx / m) * 0.001f;
-    r.oy = r.oy + (r.dy / m) * 0.001f;
-    r.oz = r.oz + (r.dz / m) * 0.001f;
+    float nx = r.dx, ny = r.dy, nz = r.dz;
+    normalize3(nx, ny, nz);
+    r.ox = r.ox + nx * 0.001f;
+    r.oy = r.oy + ny * 0.001f;
+    r.oz = r.oz + nz * 0.001f;
 }
 
 /* Distance returned by ray_intersect_sphere (ray.c:209-240) once det >= 0 is known.
@@ -117,7 +133,7 @@ __device__ __forceinline__ float sphere_distance(float B, float det)
         return (float)((double)(-B) * 0.5);
     if (!(B < 0.0f))
         return 0.0f;
-    const float wOne = (float)(((double)(-B) - sqrt((double)det)) * 0.5);
+    const float wOne = (float)(((double)(-B) - sqrt_rn_f64_pos((double)det)) * 0.5); /* det > 0 here */
     return wOne > 0.0f ? wOne : 0.0f;
 }
 
@@ -143,14 +159,14 @@ __device__ __forceinline__ T polygon_angle_sum(const float4 *vtx, uint32_t nv, f
         const float4 v = vtx[i];
         const float bx = v.x - px, by = v.y - py, bz = v.z - pz;
         const float mb = mag3(bx, by, bz);
-        const float c = dot3(ax, ay, az, bx, by, bz) / (ma * mb);
+        const float c = div_rn(dot3(ax, ay, az, bx, by, bz), ma * mb);
         if constexpr (sizeof(T) == 8)
             total += acos((double)c);
         else
             total += acosf(c);
         ax = bx; ay = by; az = bz; ma = mb;
     }
-    const float c = dot3(ax, ay, az, a0x, a0y, a0z) / (ma * m0);
+    const float c = div_rn(dot3(ax, ay, az, a0x, a0y, a0z), ma * m0);
     if constexpr (sizeof(T) == 8)
         total += acos((double)c);
     else
@@ -274,7 +290,7 @@ __device__ __forceinline__ bool polygon_inside_exact(const float4 *vtx, uint32_t
         const float4 vb = vtx[(i + 1u == nv) ? 0u : i + 1u];
         const float ax = va.x - px, ay = va.y - py, az = va.z - pz;
         const float bx = vb.x - px, by = vb.y - py, bz = vb.z - pz;
-        rot_by_cos(z, dot3(ax, ay, az, bx, by, bz) / (mag3(ax, ay, az) * mag3(bx, by, bz)));
+        rot_by_cos(z, div_rn(dot3(ax, ay, az, bx, by, bz), mag3(ax, ay, az) * mag3(bx, by, bz)));
     }
     return z.im > 0.0;
 }
@@ -330,7 +346,7 @@ __device__ __forceinline__ bool quad_inside_exact(const Quad &q)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int j = (i + 1) & 3;
-        c[i] = dot3(q.ax[i], q.ay[i], q.az[i], q.ax[j], q.ay[j], q.az[j]) / (m[i] * m[j]);
+        c[i] = div_rn(dot3(q.ax[i], q.ay[i], q.az[i], q.ax[j], q.ay[j], q.az[j]), m[i] * m[j]);
     }
     const float twopi = 6.2831853071795864769f;
     const float sf = ((acosf(c[0]) + acosf(c[1])) + acosf(c[2])) + acosf(c[3]);
@@ -499,7 +515,7 @@ __device__ __forceinline__ void intersect_all(const DevScene &S, const float4 *l
                 tl.poly_par();
                 continue;
             }
-            const float w = num / den;
+            const float w = div_rn(num, den);
             if (w < 0.0f) {
                 tl.poly_behind();
                 continue;
@@ -597,11 +613,18 @@ __device__ __forceinline__ void wave_reserve(unsigned long long *line, bool want
 
 __device__ __forceinline__ float clamp1(float v) { return v > 1.0f ? 1.0f : v; } /* color.c:44-54 */
 
-/* wave totals (ballot popcounts: they live in scalar registers, not one VGPR per lane) */
+/* Wave totals of shade nodes and spawned rays.  They are ballot popcounts taken where the whole
+ * wave has reconverged (never inside a branch some lanes skip: a lane that sits out would miss
+ * the increment), so they live in scalar registers instead of one VGPR per lane. */
 struct SpawnCounts {
     uint32_t shade_nodes = 0, refl = 0, trans = 0;
+    __device__ __forceinline__ void add(bool node, bool r, bool t)
+    {
+        shade_nodes += (uint32_t)__popcll(__ballot(node));
+        refl += (uint32_t)__popcll(__ballot(r));
+        trans += (uint32_t)__popcll(__ballot(t));
+    }
 };
-__device__ __forceinline__ uint32_t wave_count(bool p) { return (uint32_t)__popcll(__ballot(p)); }
 __device__ __forceinline__ void wave_add_total(uint64_t *stats, int slot, uint32_t total)
 {
     if (lane_id() == 0 && total != 0)
@@ -623,6 +646,7 @@ __device__ __forceinline__ void wave_add_total(uint64_t *stats, int slot, uint32
  * level        : recursion depth of this node
  * link         : value stored in the node's link word (parent<<3|slot for level >= 1,
  *                next-root<<3 for level 0); flags are OR-ed in here
+ * spawn_r/t    : whether the node asked for a reflection / transmission ray (for the counts)
  * Returns true when the lane produced a tree node (index in node_idx); otherwise `leaf` holds
  * the clamped colour of a childless node.
  */
@@ -634,9 +658,10 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
                                                 uint32_t obj, uint32_t level,
                                                 uint32_t link, uint32_t shard, uint32_t node_base,
                                                 uint32_t node_room, float leaf[3], uint32_t &node_idx,
-                                                SpawnCounts &sc, Tally<STATS> &tl)
+                                                bool &spawn_r, bool &spawn_t, Tally<STATS> &tl)
 {
     node_idx = RT_NONE;
+    spawn_r = spawn_t = false;
     if (!TILED && !hit)
         return false;
 
@@ -656,7 +681,6 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
         exc_poly = sph ? RT_NONE : __float_as_uint(g.z);
         tl.node(sph);
     }
-    sc.shade_nodes += wave_count(hit);
 
     float dfr = 0.f, dfg = 0.f, dfb = 0.f, spr = 0.f, spg = 0.f, spb = 0.f;
 #ifdef RT_ABL_NO_LIGHTS /* development ablation: price of shadow rays + Phong (wrong pixels) */
@@ -673,7 +697,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
         sh.ox = px; sh.oy = py; sh.oz = pz;
         sh.dx = lp.x - px; sh.dy = lp.y - py; sh.dz = lp.z - pz;
         sh.mag = mag3(sh.dx, sh.dy, sh.dz);
-        const float inv = 1.0f / sh.mag;
+        const float inv = recip_rn(sh.mag);
         sh.dx = sh.dx * inv; sh.dy = sh.dy * inv; sh.dz = sh.dz * inv;
         tinypush(sh);
         float sd;
@@ -700,17 +724,14 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
         float Nx, Ny, Nz;
         if (__float_as_uint(gD.y) == 1u) {
             const float nx = px - gE.x, ny = py - gE.y, nz = pz - gE.z;
-            const float m = mag3(nx, ny, nz);
-            Nx = nx / m; Ny = ny / m; Nz = nz / m;
+            Nx = nx; Ny = ny; Nz = nz;
+            normalize3(Nx, Ny, Nz);
         } else {
             Nx = gE.x; Ny = gE.y; Nz = gE.z;
         }
         /* V = normalize(eye.origin - pt) raytrace.c:318-320 */
         float Vx = eox - px, Vy = eoy - py, Vz = eoz - pz;
-        {
-            const float m = mag3(Vx, Vy, Vz);
-            Vx = Vx / m; Vy = Vy / m; Vz = Vz / m;
-        }
+        normalize3(Vx, Vy, Vz);
         const uint32_t last = (n_lights - 1u) >> 5;
         for (uint32_t c = 0; c <= last; ++c) {
             uint32_t m = (c == last) ? visible : lds_vis[c * RT_BLOCK + threadIdx.x];
@@ -720,7 +741,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
                 const float4 lp = S.light_pos[l];
                 const float4 lc = S.light_col[l];
                 float sx = lp.x - px, sy = lp.y - py, sz = lp.z - pz;
-                const float inv = 1.0f / mag3(sx, sy, sz);
+                const float inv = recip_rn(mag3(sx, sy, sz));
                 sx = sx * inv; sy = sy * inv; sz = sz * inv;
                 const float t = dot3(sx, sy, sz, Nx, Ny, Nz);
                 if (!(t <= 0.0f)) {
@@ -752,8 +773,10 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     if (is_sphere) {
         ocr = mA.x; ocg = mA.y; ocb = mA.z;
     } else {
-        const float u = (px + 15.0f) / 22.0f;   /* get_2dproject_position object3d.c:30-39 */
-        const float v = (pz + 100.0f) / 100.0f;
+        /* get_2dproject_position object3d.c:30-39; quotients by constants: any reciprocal within
+         * 1 ulp serves the correction steps of div_with */
+        const float u = div_with(px + 15.0f, 22.0f, 1.0f / 22.0f);
+        const float v = div_with(pz + 100.0f, 100.0f, 1.0f / 100.0f);
         const int xt = (int)(11.0f * u);
         const int yt = (int)(50.0f * v);
         ocr = 1.0f; ocb = 0.0f;
@@ -772,8 +795,8 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     const float kr = mC.z, kt = mC.w;
     const bool want_r = (kr != 0.0f) && (level != C.depth); /* raytrace.c:405 */
     const bool want_t = (kt != 0.0f) && (level != C.depth); /* raytrace.c:452 */
-    sc.refl += wave_count(want_r);
-    sc.trans += wave_count(want_t);
+    spawn_r = want_r;
+    spawn_t = want_t;
     if (!(want_r || want_t)) {
         leaf[0] = clamp1(outr); /* raytrace.c:562 */
         leaf[1] = clamp1(outg);
@@ -787,17 +810,14 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
         const float4 gE = S.objE[obj];
         if (is_sphere) {
             const float nx = px - gE.x, ny = py - gE.y, nz = pz - gE.z;
-            const float m = mag3(nx, ny, nz);
-            Nx = nx / m; Ny = ny / m; Nz = nz / m;
+            Nx = nx; Ny = ny; Nz = nz;
+            normalize3(Nx, Ny, Nz);
         } else {
             Nx = gE.x; Ny = gE.y; Nz = gE.z;
         }
     }
     float Vx = eox - px, Vy = eoy - py, Vz = eoz - pz;
-    {
-        const float m = mag3(Vx, Vy, Vz);
-        Vx = Vx / m; Vy = Vy / m; Vz = Vz / m;
-    }
+    normalize3(Vx, Vy, Vz);
 
     /* tree node + child rays: one reservation per wave */
     uint32_t *cnt = Wk.counters;
@@ -878,7 +898,7 @@ __device__ __forceinline__ void primary_ray(const DevCamera &C, float fu0, float
     r.ox = C.eye[0]; r.oy = C.eye[1]; r.oz = C.eye[2];
     r.dx = tx - r.ox; r.dy = ty - r.oy; r.dz = tz - r.oz;
     r.mag = mag3(r.dx, r.dy, r.dz);
-    const float inv = 1.0f / r.mag;
+    const float inv = recip_rn(r.mag);
     r.dx = r.dx * inv; r.dy = r.dy * inv; r.dz = r.dz * inv;
 }
 
@@ -998,11 +1018,13 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_primary(DevScene S, DevCam
             const bool hit = valid && (obj != RT_NONE);
             float leaf[3] = {S.bg[0], S.bg[1], S.bg[2]}; /* miss: raytrace.c:700-703 */
             uint32_t node;
+            bool sr, st_;
             const float px = r.ox + r.dx * d, py = r.oy + r.dy * d, pz = r.oz + r.dz * d;
             const PrimaryEye eye_src{C, fu0, fv0, i, j};
             const bool deferred = shade_and_spawn<TILED, STATS>(S, C, Wk, lds_poly, lds_sph, lds_vis, hit,
                                                                 eye_src, px, py, pz, obj, 0u, head << 3, shard,
-                                                                node_base, Wk.capS, leaf, node, sc, tl);
+                                                                node_base, Wk.capS, leaf, node, sr, st_, tl);
+            sc.add(hit, sr, st_);
             if (deferred) {
                 head = node; /* resolved later; chain of this pixel's roots */
             } else {
@@ -1082,13 +1104,15 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_bounce(DevScene S, DevCame
         const bool hit = active && (obj != RT_NONE);
         float leaf[3] = {S.bg[0], S.bg[1], S.bg[2]}; /* miss: kr/kt * bgColor raytrace.c:446,509,553 */
         uint32_t node;
+        bool sr, st_;
         const float px = r.ox + r.dx * d, py = r.oy + r.dy * d, pz = r.oz + r.dz * d;
         const uint32_t qi = qbase + (active ? i : 0u);
         const QueuedEye eye_src{&Wk.qA[q][qi], &Wk.qB[q][qi]};
         const bool deferred = shade_and_spawn<TILED, STATS>(S, C, Wk, lds_poly, lds_sph, lds_vis, hit, eye_src,
                                                             px, py, pz, obj, level,
                                                             ((parent >> 1) << 3) | (parent & 1u), shard, node_base,
-                                                            node_room, leaf, node, sc, tl);
+                                                            node_room, leaf, node, sr, st_, tl);
+        sc.add(hit, sr, st_);
         if (active && !deferred && (parent >> 1) < Wk.cap) {
             /* finished child colour goes straight into the parent's slot */
             const uint32_t pn = parent >> 1;
@@ -1176,6 +1200,25 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DevCamera C, DevWork Wk, D
     }
 }
 
+/* rt_hip_selftest_arith: the helpers of rt_arith.h as the kernels use them */
+__global__ __launch_bounds__(RT_BLOCK) void k_selftest_arith(const float *a, const float *b, const float *c,
+                                                             uint32_t n, float *out, double *out64)
+{
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n)
+        return;
+    const float x = a[i], y = b[i], z = c[i];
+    float nx = x, ny = y, nz = z;
+    normalize3(nx, ny, nz);
+    float *o = out + (size_t)i * 7u;
+    o[0] = sqrt_rn(x);
+    o[1] = div_rn(x, y);
+    o[2] = div_with(x, y, rcp_refined(y));
+    o[3] = nx; o[4] = ny; o[5] = nz;
+    o[6] = recip_rn(y);
+    out64[i] = sqrt_rn_f64_pos((double)x);
+}
+
 } // namespace
 
 /* ------------------------------------------------------------------------------------------ */
@@ -1246,4 +1289,11 @@ void rt_launch_resolve(const DevCamera &C, const DevWork &Wk, const DevRows &R, 
     if (grid == 0)
         grid = 1;
     k_resolve<<<(uint32_t)grid, RT_BLOCK, 0, stream>>>(C, Wk, R, d_argb, d_radiance);
+}
+
+void rt_launch_selftest_arith(const float *a, const float *b, const float *c, uint32_t n, float *out,
+                              double *out64, hipStream_t stream)
+{
+    if (n)
+        k_selftest_arith<<<(n + RT_BLOCK - 1) / RT_BLOCK, RT_BLOCK, 0, stream>>>(a, b, c, n, out, out64);
 }

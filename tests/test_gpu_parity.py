@@ -343,3 +343,59 @@ def test_device_math_is_ieee(torch_cuda):
     assert floor_or_bg.sum() > 200000
     exact = (rad.view(np.uint32) == r_o.view(np.uint32)).all(-1)
     assert (~exact & floor_or_bg).sum() <= 4
+
+
+def test_arith_helpers_are_ieee(torch_cuda):
+    """csrc/rt_arith.h: the kernels' divide / square-root sequences must round as IEEE does (the
+    reference's `/`, sqrt() and vec4_normalize on x86).  2^22 random operands across the exponent
+    range the helpers document (|x| in [2^-40, 2^40]) plus zeros, infinities, NaN, negative radicands
+    and near-one / near-power-of-two values, bit for bit against numpy's float32 / float64."""
+    torch = torch_cuda
+    rng = np.random.default_rng(0xA11CE)
+    n = 1 << 22
+    def operands():
+        mant = rng.uniform(1.0, 2.0, n).astype(np.float32)
+        expo = rng.integers(-40, 41, n)
+        sign = rng.choice(np.array([-1.0, 1.0], np.float32), n)
+        v = np.ldexp(mant, expo).astype(np.float32) * sign
+        # tight clusters: values one to three ulps around powers of two and around 1/3 scale steps
+        k = n // 8
+        base = np.ldexp(np.float32(1.0), rng.integers(-20, 21, k)).astype(np.float32)
+        v[:k] = (base.view(np.uint32) + rng.integers(-3, 4, k).astype(np.uint32)).view(np.float32)
+        return v
+    a, b, c = operands(), operands(), operands()
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, 3.0, 1e-30, 1e30], np.float32)
+    m = len(special)
+    a[-m * m:] = np.repeat(special, m)
+    b[-m * m:] = np.tile(special, m)
+    da, db, dc = (torch.from_numpy(v).cuda() for v in (a, b, c))
+    out = torch.empty((n, 7), dtype=torch.float32, device="cuda")
+    out64 = torch.empty(n, dtype=torch.float64, device="cuda")
+    rc = _lib.load().rt_hip_selftest_arith(da.data_ptr(), db.data_ptr(), dc.data_ptr(), n, out.data_ptr(),
+                                           out64.data_ptr(), None)
+    _lib.check(rc, "rt_hip_selftest_arith")
+    o, o64 = out.cpu().numpy(), out64.cpu().numpy()
+
+    def same(got, want, where, what):
+        g, w = got[where], want[where]
+        ok = (g.view(np.uint32) == w.view(np.uint32)) | (np.isnan(g) & np.isnan(w))
+        assert ok.all(), (what, int((~ok).sum()), g[~ok][:4], w[~ok][:4])
+
+    everywhere = np.ones(n, bool)
+    with np.errstate(all="ignore"):
+        same(o[:, 0], np.sqrt(a), everywhere, "sqrt_rn")                       # specials included
+        same(o[:, 1], a / b, everywhere, "div_rn")                             # specials included
+        ordinary = np.isfinite(a) & np.isfinite(b) & (b != 0) & (np.abs(b) > 1e-25) & (np.abs(b) < 1e25)
+        # without the fix-up a zero numerator may come back as +0 where IEEE gives -0 (documented)
+        same(o[:, 2], a / b, ordinary & (a != 0), "div_with")
+        assert (o[:, 2][ordinary & (a == 0)] == 0).all()
+        same(o[:, 6], np.float32(1.0) / b, ordinary, "recip_rn")
+        fin = np.isfinite(a) & np.isfinite(b) & np.isfinite(c) & ((a != 0) | (b != 0) | (c != 0))
+        fin &= (np.maximum(np.maximum(np.abs(a), np.abs(b)), np.abs(c)) < 1e18)
+        mag = np.sqrt((a * a + b * b) + c * c)
+        for k, v in enumerate((a, b, c)):
+            same(o[:, 3 + k], v / mag, fin & (mag > 1e-18) & (v != 0), "normalize3")
+            assert (o[:, 3 + k][fin & (mag > 1e-18) & (v == 0)] == 0).all()
+        pos = np.isfinite(a) & (a > 0)
+        want64 = np.sqrt(a.astype(np.float64))
+        assert (o64[pos].view(np.uint64) == want64[pos].view(np.uint64)).all()
