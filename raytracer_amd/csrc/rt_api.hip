@@ -487,14 +487,16 @@ int rt_hip_scene_upload(rt_hip_ctx *c, const rt_scene *sc)
     const uint32_t nObj = sc->nObjects, nL = sc->nLights;
     std::vector<float4> sph, planes, infos, verts;
     std::vector<uint32_t> sph_obj;
-    std::vector<float4> oA(nObj), oB(nObj), oC(nObj), oD(nObj), oE(nObj);
+    std::vector<float4> tab((size_t)2 * nL + (size_t)RT_OBJ_FIELDS * nObj);
+    float4 *orec = tab.data() + (size_t)2 * nL;
     for (uint32_t i = 0; i < nObj; ++i) {
         const rt_object3d &o = sc->objects[i];
         const rt_material &m = o.material;
         const rt_color &df = m.colors[RT_MATERIAL_DIFFUSECOLOR], &sp = m.colors[RT_MATERIAL_SPECULARCOLOR];
-        oA[i] = make_float4(df.r, df.g, df.b, m.phong_ka);
-        oB[i] = make_float4(sp.r, sp.g, sp.b, m.phong_ks);
-        oC[i] = make_float4(m.phong_kd, m.phong_ke, m.kr, m.kt);
+        float4 *rec = orec + (size_t)RT_OBJ_FIELDS * i;
+        rec[RT_OBJ_DIFFUSE] = make_float4(df.r, df.g, df.b, m.phong_ka);
+        rec[RT_OBJ_SPECULAR] = make_float4(sp.r, sp.g, sp.b, m.phong_ks);
+        rec[RT_OBJ_PHONG] = make_float4(m.phong_kd, m.phong_ke, m.kr, m.kt);
         uint32_t glist = RT_NONE;
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         if (o.geometryType == RT_GEOMETRY_SPHERE) {
@@ -522,9 +524,9 @@ int rt_hip_scene_upload(rt_hip_ctx *c, const rt_scene *sc)
                 verts.push_back(make_float4(pg.vertex[v].x, pg.vertex[v].y, pg.vertex[v].z, pg.vertex[v].w));
             g = make_float4(pg.plane.A, pg.plane.B, pg.plane.C, 0.f);
         } /* any other tag never intersects (raytrace.c:179-180): it keeps its index, no geometry */
-        oD[i] = make_float4(m.n, __builtin_bit_cast(float, (uint32_t)o.geometryType),
-                            __builtin_bit_cast(float, glist), 0.f);
-        oE[i] = g;
+        rec[RT_OBJ_GEOM] = make_float4(m.n, __builtin_bit_cast(float, (uint32_t)o.geometryType),
+                                       __builtin_bit_cast(float, glist), 0.f);
+        rec[RT_OBJ_SHAPE] = g;
     }
     const uint32_t nSph = (uint32_t)sph.size(), nPoly = (uint32_t)planes.size();
     const size_t polySlots = 2 * (size_t)nPoly + verts.size();
@@ -536,21 +538,17 @@ int rt_hip_scene_upload(rt_hip_ctx *c, const rt_scene *sc)
     poly.insert(poly.end(), planes.begin(), planes.end());
     poly.insert(poly.end(), infos.begin(), infos.end());
     poly.insert(poly.end(), verts.begin(), verts.end());
-    std::vector<float4> lp(nL), lc(nL);
     for (uint32_t l = 0; l < nL; ++l) {
         const rt_pointlight &L = sc->lights[l];
-        lp[l] = make_float4(L.position.x, L.position.y, L.position.z, L.position.w);
-        lc[l] = make_float4(L.color.r, L.color.g, L.color.b, 0.f);
+        tab[2 * l + 0] = make_float4(L.position.x, L.position.y, L.position.z, L.position.w);
+        tab[2 * l + 1] = make_float4(L.color.r, L.color.g, L.color.b, 0.f);
     }
 
     /* one blob, 256-B aligned arrays */
     struct Seg { const void *src; size_t bytes; size_t off; };
-    Seg segs[10] = {
+    Seg segs[4] = {
         {sph.data(), sph.size() * sizeof(float4), 0},   {sph_obj.data(), sph_obj.size() * sizeof(uint32_t), 0},
-        {poly.data(), poly.size() * sizeof(float4), 0}, {oA.data(), oA.size() * sizeof(float4), 0},
-        {oB.data(), oB.size() * sizeof(float4), 0},     {oC.data(), oC.size() * sizeof(float4), 0},
-        {oD.data(), oD.size() * sizeof(float4), 0},     {oE.data(), oE.size() * sizeof(float4), 0},
-        {lp.data(), lp.size() * sizeof(float4), 0},     {lc.data(), lc.size() * sizeof(float4), 0}};
+        {poly.data(), poly.size() * sizeof(float4), 0}, {tab.data(), tab.size() * sizeof(float4), 0}};
     size_t total = 0;
     for (Seg &s : segs) {
         s.off = total;
@@ -572,18 +570,15 @@ int rt_hip_scene_upload(rt_hip_ctx *c, const rt_scene *sc)
     S.sph = (const float4 *)(b + segs[0].off);
     S.sph_obj = (const uint32_t *)(b + segs[1].off);
     S.poly = (const float4 *)(b + segs[2].off);
-    S.objA = (const float4 *)(b + segs[3].off);
-    S.objB = (const float4 *)(b + segs[4].off);
-    S.objC = (const float4 *)(b + segs[5].off);
-    S.objD = (const float4 *)(b + segs[6].off);
-    S.objE = (const float4 *)(b + segs[7].off);
-    S.light_pos = (const float4 *)(b + segs[8].off);
-    S.light_col = (const float4 *)(b + segs[9].off);
+    S.tab = (const float4 *)(b + segs[3].off);
     S.nSph = nSph;
     S.nPoly = nPoly;
     S.nPolySlots = (uint32_t)polySlots;
     S.nObj = nObj;
     S.nLights = nL;
+    S.tabSlots = (uint32_t)tab.size();
+    S.tabInLds = 0;
+    S.tabInLds = (rt_scene_lds_bytes(S) + tab.size() * sizeof(float4) <= RT_LDS_TABLE_BUDGET) ? 1u : 0u;
     S.bg[0] = sc->bgColor.r; S.bg[1] = sc->bgColor.g; S.bg[2] = sc->bgColor.b;
     S.ambient[0] = sc->ambientLightColor.r;
     S.ambient[1] = sc->ambientLightColor.g;

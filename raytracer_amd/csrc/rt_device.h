@@ -37,17 +37,30 @@ struct DevScene {
                                  poly[p]            = (A,B,C,F)
                                  poly[nPoly+p]      = bits(vtx offset, nv, obj, 0)
                                  poly[2*nPoly+v]    = vertex v (x,y,z,w)              */
-    const float4 *objA;       /* [nObj] (diffuse rgb, ka)                            */
-    const float4 *objB;       /* [nObj] (specular rgb, ks)                           */
-    const float4 *objC;       /* [nObj] (kd, ke, kr, kt)                             */
-    const float4 *objD;       /* [nObj] (n, bits type, bits geometry-list index, 0)  */
-    const float4 *objE;       /* [nObj] sphere centre xyz | polygon plane normal ABC */
-    const float4 *light_pos;  /* [nLights] */
-    const float4 *light_col;  /* [nLights] */
+    const float4 *tab;        /* [tabSlots] shading tables, records of whole float4s:
+                                 tab[2*l + 0]              = light l position
+                                 tab[2*l + 1]              = light l colour
+                                 tab[2*nLights + 5*o + k]  = object o, RT_OBJ_* field k
+                                 (one 80-byte record per object: a lane that shades object o
+                                 touches one or two cache lines, not five arrays)            */
     uint32_t nSph, nPoly, nPolySlots, nObj, nLights;
+    uint32_t tabSlots;        /* 2*nLights + 5*nObj                                          */
+    uint32_t tabInLds;        /* the tables are small enough to be staged in LDS per block   */
     float bg[3];
     float ambient[3];
 };
+
+/* fields of an object record in DevScene::tab */
+enum {
+    RT_OBJ_DIFFUSE = 0, /* (diffuse rgb, ka)                                   */
+    RT_OBJ_SPECULAR,    /* (specular rgb, ks)                                  */
+    RT_OBJ_PHONG,       /* (kd, ke, kr, kt)                                    */
+    RT_OBJ_GEOM,        /* (n, bits type, bits geometry-list index, 0)         */
+    RT_OBJ_SHAPE,       /* sphere centre xyz | polygon plane normal ABC        */
+    RT_OBJ_FIELDS
+};
+#define RT_LDS_TABLE_BUDGET 20480u /* bytes of LDS per block up to which the tables are staged too
+                                      (8 blocks per CU still fit the 160 KiB) */
 
 /* Rows of one image batch, as 8-row tile rows (a wave owns an 8x8 pixel tile).
  * Tile row j of the batch covers frame rows y_first + j*y_step + [0,8), clipped to y_limit, and

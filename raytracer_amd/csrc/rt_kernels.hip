@@ -550,6 +550,24 @@ __device__ __forceinline__ void intersect_all(const DevScene &S, const float4 *l
     out_obj = ANYHIT ? (found ? 0u : RT_NONE) : (found ? best_obj : RT_NONE);
 }
 
+/* number of LDS words that hold the light-visibility bits of all but the last 32 lights */
+__host__ __device__ __forceinline__ uint32_t vis_words(uint32_t nLights)
+{
+    return nLights > 32u ? ((nLights - 1u) / 32u) * RT_BLOCK : 0u;
+}
+
+/* Light and object tables: staged in LDS behind the visibility words when they are small
+ * (DevScene::tabInLds), read from HBM / L2 otherwise.  The returned pointer is generic (flat
+ * loads), so one kernel body serves both.  Callers follow up with __syncthreads(). */
+__device__ __forceinline__ const float4 *stage_tables(const DevScene &S, uint32_t *lds_vis)
+{
+    if (!S.tabInLds)
+        return S.tab;
+    float4 *lds_tab = (float4 *)(lds_vis + vis_words(S.nLights));
+    block_copy(lds_tab, S.tab, S.tabSlots);
+    return lds_tab;
+}
+
 /* counter line of (level, shard): low word = nodes made at `level`, high word = rays queued
  * for level+1 (rt_device.h) */
 __device__ __forceinline__ unsigned long long *level_line(uint32_t *counters, uint32_t level,
@@ -653,7 +671,8 @@ __device__ __forceinline__ void wave_add_total(uint64_t *stats, int slot, uint32
 template <bool TILED, bool STATS, typename EyeSource>
 __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCamera &C,
                                                 const DevWork &Wk, const float4 *lds_poly,
-                                                float4 *lds_sph, uint32_t *lds_vis, bool hit,
+                                                float4 *lds_sph, uint32_t *lds_vis,
+                                                const float4 *tab, bool hit,
                                                 const EyeSource &eye_src, float px, float py, float pz,
                                                 uint32_t obj, uint32_t level,
                                                 uint32_t link, uint32_t shard, uint32_t node_base,
@@ -673,9 +692,10 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
      *   pass B  Phong terms of the visible lights, in light order (the sums are order-sensitive)
      * The shadow direction is rebuilt in pass B by the same expressions, hence bit-identical.
      */
+    const float4 *rec = tab + 2u * S.nLights + (hit ? obj : 0u) * (uint32_t)RT_OBJ_FIELDS; /* this object's record */
     uint32_t exc_sph = RT_NONE, exc_poly = RT_NONE;
     if (hit) {
-        const float4 g = S.objD[obj];
+        const float4 g = rec[RT_OBJ_GEOM];
         const bool sph = __float_as_uint(g.y) == 1u; /* GEOMETRY_SPHERE */
         exc_sph = sph ? __float_as_uint(g.z) : RT_NONE;
         exc_poly = sph ? RT_NONE : __float_as_uint(g.z);
@@ -691,7 +711,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     /* pass A (raytrace.c:327-347).  Visibility words of all but the last 32 lights go to LDS. */
     uint32_t visible = 0;
     for (uint32_t l = 0; l < n_lights; ++l) {
-        const float4 lp = S.light_pos[l];
+        const float4 lp = tab[2u * l];
         /* ray_create(pt, light) ray.c:29-41 */
         Ray sh;
         sh.ox = px; sh.oy = py; sh.oz = pz;
@@ -717,9 +737,9 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
 
     /* pass B (raytrace.c:349-384) */
     if (hit && n_lights != 0) {
-        const float4 gD = S.objD[obj];
-        const float4 gE = S.objE[obj];
-        const float ke = S.objC[obj].y;
+        const float4 gD = rec[RT_OBJ_GEOM];
+        const float4 gE = rec[RT_OBJ_SHAPE];
+        const float ke = rec[RT_OBJ_PHONG].y;
         /* normal: geometry.c:37-57 */
         float Nx, Ny, Nz;
         if (__float_as_uint(gD.y) == 1u) {
@@ -738,8 +758,8 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
             while (m) {
                 const uint32_t l = c * 32u + (uint32_t)__ffs((int)m) - 1u;
                 m &= m - 1u;
-                const float4 lp = S.light_pos[l];
-                const float4 lc = S.light_col[l];
+                const float4 lp = tab[2u * l];
+                const float4 lc = tab[2u * l + 1u];
                 float sx = lp.x - px, sy = lp.y - py, sz = lp.z - pz;
                 const float inv = recip_rn(mag3(sx, sy, sz));
                 sx = sx * inv; sy = sy * inv; sz = sz * inv;
@@ -762,10 +782,10 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
         return false;
 
     /* material, object colour, normal and view vector for the combine and the spawn */
-    const float4 mA = S.objA[obj];
-    const float4 mB = S.objB[obj];
-    const float4 mC = S.objC[obj];
-    const float4 mD = S.objD[obj];
+    const float4 mA = rec[RT_OBJ_DIFFUSE];
+    const float4 mB = rec[RT_OBJ_SPECULAR];
+    const float4 mC = rec[RT_OBJ_PHONG];
+    const float4 mD = rec[RT_OBJ_GEOM];
     const bool is_sphere = __float_as_uint(mD.y) == 1u;
 
     /* get_object_color object3d.c:64-117 */
@@ -807,7 +827,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     /* normal (geometry.c:37-57) and V = normalize(eye.origin - pt) (raytrace.c:318-320) again */
     float Nx, Ny, Nz;
     {
-        const float4 gE = S.objE[obj];
+        const float4 gE = rec[RT_OBJ_SHAPE];
         if (is_sphere) {
             const float nx = px - gE.x, ny = py - gE.y, nz = pz - gE.z;
             Nx = nx; Ny = ny; Nz = nz;
@@ -981,6 +1001,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_primary(DevScene S, DevCam
     float4 *lds_poly = lds;
     float4 *lds_sph = lds + S.nPolySlots;
     uint32_t *lds_vis = (uint32_t *)(lds_sph + (TILED ? (uint32_t)RT_TILE_SPHERES : S.nSph));
+    const float4 *tab = stage_tables(S, lds_vis);
     block_copy(lds_poly, S.poly, S.nPolySlots);
     if (!TILED)
         block_copy(lds_sph, S.sph, S.nSph);
@@ -1021,7 +1042,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_primary(DevScene S, DevCam
             bool sr, st_;
             const float px = r.ox + r.dx * d, py = r.oy + r.dy * d, pz = r.oz + r.dz * d;
             const PrimaryEye eye_src{C, fu0, fv0, i, j};
-            const bool deferred = shade_and_spawn<TILED, STATS>(S, C, Wk, lds_poly, lds_sph, lds_vis, hit,
+            const bool deferred = shade_and_spawn<TILED, STATS>(S, C, Wk, lds_poly, lds_sph, lds_vis, tab, hit,
                                                                 eye_src, px, py, pz, obj, 0u, head << 3, shard,
                                                                 node_base, Wk.capS, leaf, node, sr, st_, tl);
             sc.add(hit, sr, st_);
@@ -1067,6 +1088,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_bounce(DevScene S, DevCame
     if (slice * RT_BLOCK >= n)
         return; /* block-uniform */
 
+    const float4 *tab = stage_tables(S, lds_vis);
     block_copy(lds_poly, S.poly, S.nPolySlots);
     if (!TILED)
         block_copy(lds_sph, S.sph, S.nSph);
@@ -1108,7 +1130,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_bounce(DevScene S, DevCame
         const float px = r.ox + r.dx * d, py = r.oy + r.dy * d, pz = r.oz + r.dz * d;
         const uint32_t qi = qbase + (active ? i : 0u);
         const QueuedEye eye_src{&Wk.qA[q][qi], &Wk.qB[q][qi]};
-        const bool deferred = shade_and_spawn<TILED, STATS>(S, C, Wk, lds_poly, lds_sph, lds_vis, hit, eye_src,
+        const bool deferred = shade_and_spawn<TILED, STATS>(S, C, Wk, lds_poly, lds_sph, lds_vis, tab, hit, eye_src,
                                                             px, py, pz, obj, level,
                                                             ((parent >> 1) << 3) | (parent & 1u), shard, node_base,
                                                             node_room, leaf, node, sr, st_, tl);
@@ -1228,9 +1250,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_selftest_arith(const float *a, con
 size_t rt_scene_lds_bytes(const DevScene &S)
 {
     const uint32_t sph = S.nSph < RT_TILE_SPHERES ? S.nSph : RT_TILE_SPHERES;
-    /* + one visibility word per thread for every full group of 32 lights before the last group */
-    const uint32_t vis_words = S.nLights > 32u ? ((S.nLights - 1u) / 32u) * RT_BLOCK : 0u;
-    return (size_t)(S.nPolySlots + sph) * sizeof(float4) + (size_t)vis_words * sizeof(uint32_t);
+    /* + one visibility word per thread for every full group of 32 lights before the last group,
+     * + the light / object tables when they are staged */
+    return (size_t)(S.nPolySlots + sph) * sizeof(float4) + (size_t)vis_words(S.nLights) * sizeof(uint32_t) +
+           (S.tabInLds ? (size_t)S.tabSlots * sizeof(float4) : 0);
 }
 
 void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
@@ -1248,12 +1271,37 @@ void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk,
     }
 }
 
-static uint32_t queue_grid(const DevWork &Wk)
+/*
+ * Grid of a queue-draining kernel: RT_SHARDS shards x slices, grid-strided over each shard's
+ * entries.  The grid is exactly one resident set - (blocks the kernel fits per CU) x (CUs),
+ * rounded down to whole shards: a few blocks more and they would run as a second round after the
+ * first has drained, doubling a latency-bound kernel (measured with 2048 blocks at 7 per CU).
+ */
+static uint32_t queue_grid(const DevWork &Wk, const void *kernel, size_t lds)
 {
-    /* RT_SHARDS shards x slices; 2048 blocks = 8 per CU, the rest is grid-strided */
-    uint32_t slices = (Wk.capS + RT_BLOCK - 1) / RT_BLOCK;
-    if (slices > 2048u / RT_SHARDS)
-        slices = 2048u / RT_SHARDS;
+    struct Entry { const void *kernel; size_t lds; int device; uint32_t blocks; };
+    static Entry cache[16];
+    static int ncache = 0;
+    int device = 0;
+    (void)hipGetDevice(&device);
+    uint32_t resident = 0;
+    for (int i = 0; i < ncache; ++i)
+        if (cache[i].kernel == kernel && cache[i].lds == lds && cache[i].device == device)
+            resident = cache[i].blocks;
+    if (!resident) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RT_BLOCK, lds) != hipSuccess || per_cu < 1)
+            per_cu = 4;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1)
+            cus = 256;
+        resident = (uint32_t)per_cu * (uint32_t)cus;
+        if (ncache < 16)
+            cache[ncache++] = {kernel, lds, device, resident};
+    }
+    uint32_t slices = resident / RT_SHARDS;
+    const uint32_t most = (Wk.capS + RT_BLOCK - 1) / RT_BLOCK;
+    if (slices > most)
+        slices = most;
     if (slices < 1)
         slices = 1;
     return slices * RT_SHARDS;
@@ -1262,21 +1310,18 @@ static uint32_t queue_grid(const DevWork &Wk)
 void rt_launch_bounce(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t level,
                       bool stats, hipStream_t stream)
 {
-    const uint32_t grid = queue_grid(Wk);
     const size_t lds = rt_scene_lds_bytes(S);
     const bool tiled = S.nSph > RT_TILE_SPHERES;
-    if (tiled) {
-        if (stats) k_bounce<true, true><<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, level);
-        else       k_bounce<true, false><<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, level);
-    } else {
-        if (stats) k_bounce<false, true><<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, level);
-        else       k_bounce<false, false><<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, level);
-    }
+    void (*kernel)(DevScene, DevCamera, DevWork, uint32_t) =
+        tiled ? (stats ? k_bounce<true, true> : k_bounce<true, false>)
+              : (stats ? k_bounce<false, true> : k_bounce<false, false>);
+    const uint32_t grid = queue_grid(Wk, (const void *)kernel, lds);
+    kernel<<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, level);
 }
 
 void rt_launch_fold(const DevWork &Wk, uint32_t level, hipStream_t stream)
 {
-    k_fold<<<queue_grid(Wk), RT_BLOCK, 0, stream>>>(Wk, level);
+    k_fold<<<queue_grid(Wk, (const void *)k_fold, 0), RT_BLOCK, 0, stream>>>(Wk, level);
 }
 
 void rt_launch_resolve(const DevCamera &C, const DevWork &Wk, const DevRows &R, uint32_t *d_argb,

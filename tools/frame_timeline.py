@@ -1,0 +1,14 @@
+#!/usr/bin/env python3
+"""Per-kernel timeline of the last full frame in a rocprofv3 --kernel-trace directory."""
+import csv, glob, sys
+d = sys.argv[1]
+rows = list(csv.DictReader(open(glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0])))
+ks = sorted((r for r in rows if "k_" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(ks) if "k_primary<false, false>" in r["Kernel_Name"] or "k_primary<true, false>" in r["Kernel_Name"]]
+s, e = idx[-2], idx[-1]
+t0 = int(ks[s]["Start_Timestamp"])
+for r in ks[s:e]:
+    st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    name = r["Kernel_Name"].split("::")[-1][:28]
+    print(f"{name:30s} start {(st - t0) / 1e3:9.1f}  dur {(en - st) / 1e3:8.1f} us  grid {r['Grid_Size_X']}x{r['Grid_Size_Y']} vgpr {r['VGPR_Count']}")
+print("frame period", (int(ks[e]["Start_Timestamp"]) - t0) / 1e3, "us")
