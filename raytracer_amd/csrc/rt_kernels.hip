@@ -76,6 +76,33 @@ template <> struct Tally<true> {
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 
+/* Development build (-DRT_PHASE_CLOCKS, tools/phase_probe.py): wave cycles per phase of k_bounce,
+ * read with s_memtime after draining the memory counters, summed into the statistic slots the
+ * plain build leaves unused (ST_SPH_TESTS + phase).  Compiles to nothing otherwise. */
+struct PhaseClock {
+#ifdef RT_PHASE_CLOCKS
+    unsigned long long last = 0, acc[10] = {};
+    __device__ __forceinline__ void start() { __builtin_amdgcn_s_waitcnt(0); last = clock64(); }
+    __device__ __forceinline__ void mark(int k)
+    {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long t = clock64();
+        acc[k] += t - last;
+        last = t;
+    }
+    __device__ __forceinline__ void flush(uint64_t *st)
+    {
+        if (lane_id() == 0)
+            for (int k = 0; k < 10; ++k)
+                atomicAdd((unsigned long long *)&st[ST_SPH_TESTS + k], acc[k]);
+    }
+#else
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void flush(uint64_t *) {}
+#endif
+};
+
 /* sum a per-lane counter over the wave and add it to a 64-bit global statistic */
 __device__ __forceinline__ void wave_add_stat(uint64_t *stats, int slot, uint32_t v)
 {
@@ -677,7 +704,8 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
                                                 uint32_t obj, uint32_t level,
                                                 uint32_t link, uint32_t shard, uint32_t node_base,
                                                 uint32_t node_room, float leaf[3], uint32_t &node_idx,
-                                                bool &spawn_r, bool &spawn_t, Tally<STATS> &tl)
+                                                bool &spawn_r, bool &spawn_t, Tally<STATS> &tl,
+                                                PhaseClock &pc)
 {
     node_idx = RT_NONE;
     spawn_r = spawn_t = false;
@@ -731,6 +759,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
             visible = 0;
         }
     }
+    pc.mark(2);
     /* the eye ray's origin, back from where it is kept (cannot be merged with the first read) */
     float eox, eoy, eoz;
     eye_src.origin(eox, eoy, eoz);
@@ -778,6 +807,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
             }
         }
     }
+    pc.mark(3);
     if (!hit)
         return false;
 
@@ -839,11 +869,13 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     float Vx = eox - px, Vy = eoy - py, Vz = eoz - pz;
     normalize3(Vx, Vy, Vz);
 
+    pc.mark(4);
     /* tree node + child rays: one reservation per wave */
     uint32_t *cnt = Wk.counters;
     uint32_t local, slot_r, slot_t;
     wave_reserve(level_line(cnt, level, shard), want_r, want_t, node_room, Wk.capS, &cnt[CNT_OVERFLOW + level],
                  local, slot_r, slot_t);
+    pc.mark(5);
     if (local == RT_NONE) { /* overflow: the batch will be re-rendered in smaller pieces */
         leaf[0] = leaf[1] = leaf[2] = 0.0f;
         return false;
@@ -901,6 +933,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
         Wk.qA[nq][qbase + slot_t] = make_float4(tr.ox, tr.oy, tr.oz, tr.mag);
         Wk.qB[nq][qbase + slot_t] = make_float4(tr.dx, tr.dy, tr.dz, __uint_as_float((node << 1) | 1u));
     }
+    pc.mark(6);
     return true;
 }
 
@@ -1026,6 +1059,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_primary(DevScene S, DevCam
     uint32_t head = RT_LINK_NONE;
     SpawnCounts sc;
     Tally<STATS> tl;
+    PhaseClock pc; /* unused here */
 
     for (uint32_t j = 0; j < C.sqrtSpp; ++j) {
         for (uint32_t i = 0; i < C.sqrtSpp; ++i) {
@@ -1044,7 +1078,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_primary(DevScene S, DevCam
             const PrimaryEye eye_src{C, fu0, fv0, i, j};
             const bool deferred = shade_and_spawn<TILED, STATS>(S, C, Wk, lds_poly, lds_sph, lds_vis, tab, hit,
                                                                 eye_src, px, py, pz, obj, 0u, head << 3, shard,
-                                                                node_base, Wk.capS, leaf, node, sr, st_, tl);
+                                                                node_base, Wk.capS, leaf, node, sr, st_, tl, pc);
             sc.add(hit, sr, st_);
             if (deferred) {
                 head = node; /* resolved later; chain of this pixel's roots */
@@ -1070,7 +1104,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_primary(DevScene S, DevCam
 /* k_bounce: one queued secondary ray per lane (reflection / transmission of level-1 nodes)    */
 /* ------------------------------------------------------------------------------------------ */
 template <bool TILED, bool STATS>
-__global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_bounce(DevScene S, DevCamera C, DevWork Wk,
+__global__ __launch_bounds__(RT_BLOCK, 6) void k_bounce(DevScene S, DevCamera C, DevWork Wk,
                                                      uint32_t level)
 {
     extern __shared__ __attribute__((aligned(16))) float4 lds[];
@@ -1106,23 +1140,47 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_bounce(DevScene S, DevCame
     const uint32_t q = level & 1u;
     SpawnCounts sc;
     Tally<STATS> tl;
+    PhaseClock pc;
+    /*
+     * The queue entry of the NEXT iteration is fetched before this iteration's work and is made to
+     * land before this iteration's stores are issued (the empty asm below "uses" it there).  Waits
+     * on gfx950 count loads and stores together and in order, so without that the next load's wait
+     * would also sit out the write latency of every store issued before it: measured, entry load
+     * and store drain were 64 % of an iteration's ~13k cycles, the trace-and-shade work itself 36 %.
+     */
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 na = zero4, nb = zero4;
+    if (slice * RT_BLOCK + threadIdx.x < n) {
+        na = Wk.qA[q][qbase + slice * RT_BLOCK + threadIdx.x];
+        nb = Wk.qB[q][qbase + slice * RT_BLOCK + threadIdx.x];
+    }
     for (uint32_t base = slice * RT_BLOCK; base < n; base += nslices * RT_BLOCK) {
         const uint32_t i = base + threadIdx.x;
         const bool active = i < n;
+        pc.start();
         Ray r;
         uint32_t parent = 0;
+        const float4 a = na, b = nb;
+        {
+            const uint32_t inext = i + nslices * RT_BLOCK;
+            if (inext < n) {
+                na = Wk.qA[q][qbase + inext];
+                nb = Wk.qB[q][qbase + inext];
+            }
+        }
         if (active) {
-            const float4 a = Wk.qA[q][qbase + i], b = Wk.qB[q][qbase + i];
             r.ox = a.x; r.oy = a.y; r.oz = a.z; r.mag = a.w;
             r.dx = b.x; r.dy = b.y; r.dz = b.z;
             parent = __float_as_uint(b.w);
         } else {
             r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.mag = 0.0f;
         }
+        pc.mark(0);
         float d;
         uint32_t obj;
         intersect_all<TILED, true, false, STATS>(S, lds_poly, lds_sph, active, r, RT_NONE, RT_NONE, d, obj,
                                                  tl);
+        pc.mark(1);
         const bool hit = active && (obj != RT_NONE);
         float leaf[3] = {S.bg[0], S.bg[1], S.bg[2]}; /* miss: kr/kt * bgColor raytrace.c:446,509,553 */
         uint32_t node;
@@ -1133,16 +1191,20 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_bounce(DevScene S, DevCame
         const bool deferred = shade_and_spawn<TILED, STATS>(S, C, Wk, lds_poly, lds_sph, lds_vis, tab, hit, eye_src,
                                                             px, py, pz, obj, level,
                                                             ((parent >> 1) << 3) | (parent & 1u), shard, node_base,
-                                                            node_room, leaf, node, sr, st_, tl);
+                                                            node_room, leaf, node, sr, st_, tl, pc);
         sc.add(hit, sr, st_);
+        asm volatile("" : "+v"(na.x), "+v"(na.y), "+v"(na.z), "+v"(na.w), "+v"(nb.x), "+v"(nb.y), "+v"(nb.z),
+                          "+v"(nb.w)); /* next entry has landed */
         if (active && !deferred && (parent >> 1) < Wk.cap) {
             /* finished child colour goes straight into the parent's slot */
             const uint32_t pn = parent >> 1;
             float *dst = (float *)((parent & 1u) ? &Wk.nodeC[pn] : &Wk.nodeB[pn]);
             dst[0] = leaf[0]; dst[1] = leaf[1]; dst[2] = leaf[2];
         }
+        pc.mark(7);
     }
     uint64_t *st = (uint64_t *)(Wk.counters + CNT_STATS + shard * CNT_STATS_STRIDE);
+    pc.flush(st);
     wave_add_total(st, ST_KB_SHADE_NODES, sc.shade_nodes);
     wave_add_total(st, ST_KB_REFL, sc.refl);
     wave_add_total(st, ST_KB_TRANS, sc.trans);
