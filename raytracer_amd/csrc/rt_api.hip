@@ -415,16 +415,16 @@ int rt_hip_ctx_create(rt_hip_ctx **out, int device, uint64_t max_queue_rays)
         delete c;
         return rc;
     }
-    /* one blob: 4 queue arrays + 3 node arrays of cap float4 each */
+    /* one blob: 4 queue arrays + 3 node arrays of cap float4 each + one of cap float2 */
     const size_t arr = align_up(cap * sizeof(float4), 256);
-    hipError_t e = hipMalloc(&c->work_blob, arr * 7);
+    hipError_t e = hipMalloc(&c->work_blob, arr * 7 + arr / 2);
     if (e == hipSuccess)
         e = hipMalloc((void **)&c->d_counters, (size_t)kMaxBatches * RT_COUNTER_WORDS * sizeof(uint32_t));
     if (e == hipSuccess)
         e = hipHostMalloc((void **)&c->h_counters, (size_t)kMaxBatches * RT_COUNTER_WORDS * sizeof(uint32_t),
                           hipHostMallocDefault);
     if (e != hipSuccess) {
-        set_err("allocating %zu bytes of queue memory failed: %s", arr * 7, hipGetErrorString(e));
+        set_err("allocating %zu bytes of queue memory failed: %s", arr * 7 + arr / 2, hipGetErrorString(e));
         rt_hip_ctx_destroy(c);
         return -(int)e;
     }
@@ -434,8 +434,9 @@ int rt_hip_ctx_create(rt_hip_ctx **out, int device, uint64_t max_queue_rays)
     c->W.qA[1] = (float4 *)(p + 2 * arr);
     c->W.qB[1] = (float4 *)(p + 3 * arr);
     c->W.nodeA = (float4 *)(p + 4 * arr);
-    c->W.nodeB = (float4 *)(p + 5 * arr);
-    c->W.nodeC = (float4 *)(p + 6 * arr);
+    c->W.childR = (float4 *)(p + 5 * arr);
+    c->W.childT = (float4 *)(p + 6 * arr);
+    c->W.nodeK = (float2 *)(p + 7 * arr); /* half an array */
     c->W.cap = (uint32_t)cap;
     c->W.capS = (uint32_t)(cap / RT_SHARDS);
     *out = c;
@@ -578,11 +579,17 @@ int rt_hip_scene_upload(rt_hip_ctx *c, const rt_scene *sc)
     S.nLights = nL;
     S.tabSlots = (uint32_t)tab.size();
     S.tabInLds = 0;
-    S.tabInLds = (rt_scene_lds_bytes(S) + tab.size() * sizeof(float4) <= RT_LDS_TABLE_BUDGET) ? 1u : 0u;
+    S.tabInLds = (nSph <= RT_TILE_SPHERES &&
+                  rt_scene_lds_bytes(S) + tab.size() * sizeof(float4) <= RT_LDS_TABLE_BUDGET) ? 1u : 0u;
     S.bg[0] = sc->bgColor.r; S.bg[1] = sc->bgColor.g; S.bg[2] = sc->bgColor.b;
     S.ambient[0] = sc->ambientLightColor.r;
     S.ambient[1] = sc->ambientLightColor.g;
     S.ambient[2] = sc->ambientLightColor.b;
+    if (rt_scene_lds_bytes(S) + 6u * RT_BLOCK * sizeof(float) > 65536u) {
+        set_err("scene needs %zu bytes of LDS per block (polygon data, sphere tile, %u lights), limit is 64 KiB",
+                rt_scene_lds_bytes(S) + 6u * RT_BLOCK * sizeof(float), nL);
+        return RT_E_INVALID;
+    }
     c->have_scene = true;
     return 0;
 }

@@ -76,9 +76,12 @@ struct DevRows {
 struct DevWork {
     float4 *qA[2];        /* ray queues, ping-pong by level parity: (ox,oy,oz,magnitude) */
     float4 *qB[2];        /*                                         (dx,dy,dz,bits parent<<1|slot) */
-    float4 *nodeA;        /* (local rgb, kr)                                           */
-    float4 *nodeB;        /* (reflection child rgb, kt)                                */
-    float4 *nodeC;        /* (transmission child rgb, bits link)                       */
+    float4 *nodeA;        /* (local rgb, kr)                        written when the node is made */
+    float2 *nodeK;        /* (kt, bits link)                        written when the node is made */
+    float4 *childR;       /* (reflection child rgb, -)   written by the child, as a whole float4:  */
+    float4 *childT;       /* (transmission child rgb, -) consecutive rays have consecutive parents,
+                             so a wave's results are full-line stores (12-byte pieces of a shared
+                             float4 made every store a partial-sector read-modify-write)          */
     float4 *pixAcc;       /* per pixel of the batch: (immediate sum rgb, bits head)    */
     uint32_t *counters;   /* counter block of this batch (layout below)                */
     uint32_t cap;         /* entries per queue / node pool                             */

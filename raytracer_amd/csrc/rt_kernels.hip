@@ -77,15 +77,16 @@ template <> struct Tally<true> {
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 
 /* Development build (-DRT_PHASE_CLOCKS, tools/phase_probe.py): wave cycles per phase of k_bounce,
- * read with s_memtime after draining the memory counters, summed into the statistic slots the
+ * read with s_memtime, summed into the statistic slots the
  * plain build leaves unused (ST_SPH_TESTS + phase).  Compiles to nothing otherwise. */
 struct PhaseClock {
 #ifdef RT_PHASE_CLOCKS
     unsigned long long last = 0, acc[10] = {};
-    __device__ __forceinline__ void start() { __builtin_amdgcn_s_waitcnt(0); last = clock64(); }
+    /* the clock read waits for outstanding LDS / scalar loads only: vector-memory stalls are charged
+     * to the phase whose instructions actually wait for them, as in the plain build */
+    __device__ __forceinline__ void start() { last = clock64(); }
     __device__ __forceinline__ void mark(int k)
     {
-        __builtin_amdgcn_s_waitcnt(0);
         const unsigned long long t = clock64();
         acc[k] += t - last;
         last = t;
@@ -448,6 +449,13 @@ __device__ __forceinline__ float phong_pow(float s, float ke)
 }
 
 /* Cooperative copy of n float4 from HBM to LDS by the whole block. */
+/* float4 slots of the sphere region of LDS: one tile, or (untiled) all spheres followed by their
+ * object indices (sph_obj), so that the closest-hit search never waits on a global load */
+__host__ __device__ __forceinline__ uint32_t sphere_slots(uint32_t nSph)
+{
+    return nSph > RT_TILE_SPHERES ? (uint32_t)RT_TILE_SPHERES : nSph + (nSph + 3u) / 4u;
+}
+
 __device__ __forceinline__ void block_copy(float4 *dst, const float4 *src, uint32_t n)
 {
     for (uint32_t i = threadIdx.x; i < n; i += RT_BLOCK)
@@ -526,8 +534,12 @@ __device__ __forceinline__ void intersect_all(const DevScene &S, const float4 *l
     }
 
     uint32_t best_obj = RT_NONE;
-    if (!ANYHIT && found)
-        best_obj = S.sph_obj[best_k];
+    if (!ANYHIT && found) {
+        if (TILED)
+            best_obj = S.sph_obj[best_k];
+        else
+            best_obj = ((const uint32_t *)(lds_sph + S.nSph))[best_k];
+    }
 
     if (active && !(ANYHIT && !STATS && found)) {
         for (uint32_t p = 0; p < S.nPoly; ++p) {
@@ -584,15 +596,25 @@ __host__ __device__ __forceinline__ uint32_t vis_words(uint32_t nLights)
 }
 
 /* Light and object tables: staged in LDS behind the visibility words when they are small
- * (DevScene::tabInLds), read from HBM / L2 otherwise.  The returned pointer is generic (flat
- * loads), so one kernel body serves both.  Callers follow up with __syncthreads(). */
-__device__ __forceinline__ const float4 *stage_tables(const DevScene &S, uint32_t *lds_vis)
+ * (DevScene::tabInLds, kernels instantiated with TABLDS), read from HBM / L2 otherwise.  The
+ * choice is a template parameter so that the LDS case compiles to ds_read: through one generic
+ * pointer every table read is a flat_load, whose wait is vmcnt(0) - it sits out every global
+ * store and prefetch in flight (measured: that serialised k_bounce). */
+template <bool TABLDS> struct Tables {
+    const float4 *p;
+    __device__ __forceinline__ float4 operator[](uint32_t i) const { return p[i]; }
+};
+/* callers follow up with __syncthreads() */
+template <bool TABLDS>
+__device__ __forceinline__ Tables<TABLDS> stage_tables(const DevScene &S, uint32_t *lds_vis)
 {
-    if (!S.tabInLds)
-        return S.tab;
-    float4 *lds_tab = (float4 *)(lds_vis + vis_words(S.nLights));
-    block_copy(lds_tab, S.tab, S.tabSlots);
-    return lds_tab;
+    if constexpr (TABLDS) {
+        float4 *lds_tab = (float4 *)(lds_vis + vis_words(S.nLights));
+        block_copy(lds_tab, S.tab, S.tabSlots);
+        return Tables<TABLDS>{lds_tab};
+    } else {
+        return Tables<TABLDS>{S.tab};
+    }
 }
 
 /* counter line of (level, shard): low word = nodes made at `level`, high word = rays queued
@@ -695,11 +717,11 @@ __device__ __forceinline__ void wave_add_total(uint64_t *stats, int slot, uint32
  * Returns true when the lane produced a tree node (index in node_idx); otherwise `leaf` holds
  * the clamped colour of a childless node.
  */
-template <bool TILED, bool STATS, typename EyeSource>
+template <bool TILED, bool STATS, bool TABLDS, typename EyeSource>
 __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCamera &C,
                                                 const DevWork &Wk, const float4 *lds_poly,
                                                 float4 *lds_sph, uint32_t *lds_vis,
-                                                const float4 *tab, bool hit,
+                                                const Tables<TABLDS> &tab, bool hit,
                                                 const EyeSource &eye_src, float px, float py, float pz,
                                                 uint32_t obj, uint32_t level,
                                                 uint32_t link, uint32_t shard, uint32_t node_base,
@@ -720,10 +742,10 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
      *   pass B  Phong terms of the visible lights, in light order (the sums are order-sensitive)
      * The shadow direction is rebuilt in pass B by the same expressions, hence bit-identical.
      */
-    const float4 *rec = tab + 2u * S.nLights + (hit ? obj : 0u) * (uint32_t)RT_OBJ_FIELDS; /* this object's record */
+    const uint32_t rec = 2u * S.nLights + (hit ? obj : 0u) * (uint32_t)RT_OBJ_FIELDS; /* this object's record */
     uint32_t exc_sph = RT_NONE, exc_poly = RT_NONE;
     if (hit) {
-        const float4 g = rec[RT_OBJ_GEOM];
+        const float4 g = tab[rec + RT_OBJ_GEOM];
         const bool sph = __float_as_uint(g.y) == 1u; /* GEOMETRY_SPHERE */
         exc_sph = sph ? __float_as_uint(g.z) : RT_NONE;
         exc_poly = sph ? RT_NONE : __float_as_uint(g.z);
@@ -766,9 +788,9 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
 
     /* pass B (raytrace.c:349-384) */
     if (hit && n_lights != 0) {
-        const float4 gD = rec[RT_OBJ_GEOM];
-        const float4 gE = rec[RT_OBJ_SHAPE];
-        const float ke = rec[RT_OBJ_PHONG].y;
+        const float4 gD = tab[rec + RT_OBJ_GEOM];
+        const float4 gE = tab[rec + RT_OBJ_SHAPE];
+        const float ke = tab[rec + RT_OBJ_PHONG].y;
         /* normal: geometry.c:37-57 */
         float Nx, Ny, Nz;
         if (__float_as_uint(gD.y) == 1u) {
@@ -812,10 +834,10 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
         return false;
 
     /* material, object colour, normal and view vector for the combine and the spawn */
-    const float4 mA = rec[RT_OBJ_DIFFUSE];
-    const float4 mB = rec[RT_OBJ_SPECULAR];
-    const float4 mC = rec[RT_OBJ_PHONG];
-    const float4 mD = rec[RT_OBJ_GEOM];
+    const float4 mA = tab[rec + RT_OBJ_DIFFUSE];
+    const float4 mB = tab[rec + RT_OBJ_SPECULAR];
+    const float4 mC = tab[rec + RT_OBJ_PHONG];
+    const float4 mD = tab[rec + RT_OBJ_GEOM];
     const bool is_sphere = __float_as_uint(mD.y) == 1u;
 
     /* get_object_color object3d.c:64-117 */
@@ -857,7 +879,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     /* normal (geometry.c:37-57) and V = normalize(eye.origin - pt) (raytrace.c:318-320) again */
     float Nx, Ny, Nz;
     {
-        const float4 gE = rec[RT_OBJ_SHAPE];
+        const float4 gE = tab[rec + RT_OBJ_SHAPE];
         if (is_sphere) {
             const float nx = px - gE.x, ny = py - gE.y, nz = pz - gE.z;
             Nx = nx; Ny = ny; Nz = nz;
@@ -883,11 +905,13 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     const uint32_t node = node_base + local;
     node_idx = node;
     Wk.nodeA[node] = make_float4(outr, outg, outb, kr);
-    Wk.nodeB[node] = make_float4(0.f, 0.f, 0.f, kt);
-    Wk.nodeC[node] = make_float4(0.f, 0.f, 0.f,
-                                 __uint_as_float(link | (want_r ? 2u : 0u) | (want_t ? 4u : 0u)));
+    Wk.nodeK[node] = make_float2(kt, __uint_as_float(link | (want_r ? 2u : 0u) | (want_t ? 4u : 0u)));
 
-    const uint32_t nq = (level + 1) & 1u;
+    /* queue of the next level: picked with selects - indexing the kernel-argument pointer array
+     * with a run-time value makes the compiler re-load the pointer from memory at every use */
+    const bool odd_next = ((level + 1) & 1u) != 0;
+    float4 *const outA = odd_next ? Wk.qA[1] : Wk.qA[0];
+    float4 *const outB = odd_next ? Wk.qB[1] : Wk.qB[0];
     const uint32_t qbase = shard * Wk.capS;
 
     /* reflection ray raytrace.c:408-425 */
@@ -900,8 +924,8 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
         tinypush(rr);
     }
     if (slot_r != RT_NONE) {
-        Wk.qA[nq][qbase + slot_r] = make_float4(rr.ox, rr.oy, rr.oz, rr.mag);
-        Wk.qB[nq][qbase + slot_r] = make_float4(rr.dx, rr.dy, rr.dz, __uint_as_float((node << 1) | 0u));
+        outA[qbase + slot_r] = make_float4(rr.ox, rr.oy, rr.oz, rr.mag);
+        outB[qbase + slot_r] = make_float4(rr.dx, rr.dy, rr.dz, __uint_as_float((node << 1) | 0u));
     }
     /* transmission ray raytrace.c:455-537 */
     Ray tr;
@@ -930,8 +954,8 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
         tinypush(tr);
     }
     if (slot_t != RT_NONE) {
-        Wk.qA[nq][qbase + slot_t] = make_float4(tr.ox, tr.oy, tr.oz, tr.mag);
-        Wk.qB[nq][qbase + slot_t] = make_float4(tr.dx, tr.dy, tr.dz, __uint_as_float((node << 1) | 1u));
+        outA[qbase + slot_t] = make_float4(tr.ox, tr.oy, tr.oz, tr.mag);
+        outB[qbase + slot_t] = make_float4(tr.dx, tr.dy, tr.dz, __uint_as_float((node << 1) | 1u));
     }
     pc.mark(6);
     return true;
@@ -975,21 +999,30 @@ struct PrimaryEye {
         x = r.dx; y = r.dy; z = r.dz;
     }
 };
-struct QueuedEye {
-    const float4 *qa, *qb; /* this lane's queue entry */
+/* k_bounce parks the ray in LDS (one column per thread, SoA rows: conflict-free) rather than
+ * re-reading the queue: on gfx950 a global load issued after the previous iteration's stores waits
+ * for their write acknowledgements as well (one in-order counter), an LDS read does not. */
+#define RT_EYE_STASH_FLOATS (6u * RT_BLOCK)
+struct StashedEye {
+    const float *lds_eye;
+    __device__ __forceinline__ static void park(float *lds_eye, const Ray &r)
+    {
+        float *c = lds_eye + threadIdx.x;
+        c[0 * RT_BLOCK] = r.ox; c[1 * RT_BLOCK] = r.oy; c[2 * RT_BLOCK] = r.oz;
+        c[3 * RT_BLOCK] = r.dx; c[4 * RT_BLOCK] = r.dy; c[5 * RT_BLOCK] = r.dz;
+    }
     __device__ __forceinline__ void origin(float &x, float &y, float &z) const
     {
-        const float4 *p = qa;
-        asm volatile("" : "+v"(p));
-        const float4 a = *p;
-        x = a.x; y = a.y; z = a.z;
+        uint32_t t = threadIdx.x;
+        asm volatile("" : "+v"(t)); /* opaque index (the pointer stays an LDS pointer): no forwarding
+                                       of the parked registers */
+        x = lds_eye[t + 0 * RT_BLOCK]; y = lds_eye[t + 1 * RT_BLOCK]; z = lds_eye[t + 2 * RT_BLOCK];
     }
     __device__ __forceinline__ void direction(float &x, float &y, float &z) const
     {
-        const float4 *p = qb;
-        asm volatile("" : "+v"(p));
-        const float4 b = *p;
-        x = b.x; y = b.y; z = b.z;
+        uint32_t t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        x = lds_eye[t + 3 * RT_BLOCK]; y = lds_eye[t + 4 * RT_BLOCK]; z = lds_eye[t + 5 * RT_BLOCK];
     }
 };
 
@@ -1026,18 +1059,21 @@ __device__ __forceinline__ void flush_tally(uint64_t *st, Tally<STATS> &tl, bool
 /* ------------------------------------------------------------------------------------------ */
 /* k_primary: get_pixel_color + get_ray_color + depth-0 get_shade_color_phong, fused           */
 /* ------------------------------------------------------------------------------------------ */
-template <bool TILED, bool STATS>
+template <bool TILED, bool STATS, bool TABLDS>
 __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_primary(DevScene S, DevCamera C, DevWork Wk,
                                                       DevRows R)
 {
     extern __shared__ __attribute__((aligned(16))) float4 lds[];
     float4 *lds_poly = lds;
     float4 *lds_sph = lds + S.nPolySlots;
-    uint32_t *lds_vis = (uint32_t *)(lds_sph + (TILED ? (uint32_t)RT_TILE_SPHERES : S.nSph));
-    const float4 *tab = stage_tables(S, lds_vis);
+    uint32_t *lds_vis = (uint32_t *)(lds_sph + sphere_slots(S.nSph));
+    const Tables<TABLDS> tab = stage_tables<TABLDS>(S, lds_vis);
     block_copy(lds_poly, S.poly, S.nPolySlots);
-    if (!TILED)
+    if (!TILED) {
         block_copy(lds_sph, S.sph, S.nSph);
+        for (uint32_t k = threadIdx.x; k < S.nSph; k += RT_BLOCK)
+            ((uint32_t *)(lds_sph + S.nSph))[k] = S.sph_obj[k];
+    }
     __syncthreads();
 
     /* a wave owns an 8x8 pixel tile; the block is 4 tiles side by side (32x8 pixels) */
@@ -1076,7 +1112,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_primary(DevScene S, DevCam
             bool sr, st_;
             const float px = r.ox + r.dx * d, py = r.oy + r.dy * d, pz = r.oz + r.dz * d;
             const PrimaryEye eye_src{C, fu0, fv0, i, j};
-            const bool deferred = shade_and_spawn<TILED, STATS>(S, C, Wk, lds_poly, lds_sph, lds_vis, tab, hit,
+            const bool deferred = shade_and_spawn<TILED, STATS, TABLDS>(S, C, Wk, lds_poly, lds_sph, lds_vis, tab, hit,
                                                                 eye_src, px, py, pz, obj, 0u, head << 3, shard,
                                                                 node_base, Wk.capS, leaf, node, sr, st_, tl, pc);
             sc.add(hit, sr, st_);
@@ -1103,14 +1139,15 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_primary(DevScene S, DevCam
 /* ------------------------------------------------------------------------------------------ */
 /* k_bounce: one queued secondary ray per lane (reflection / transmission of level-1 nodes)    */
 /* ------------------------------------------------------------------------------------------ */
-template <bool TILED, bool STATS>
+template <bool TILED, bool STATS, bool TABLDS>
 __global__ __launch_bounds__(RT_BLOCK, 6) void k_bounce(DevScene S, DevCamera C, DevWork Wk,
                                                      uint32_t level)
 {
     extern __shared__ __attribute__((aligned(16))) float4 lds[];
-    float4 *lds_poly = lds;
-    float4 *lds_sph = lds + S.nPolySlots;
-    uint32_t *lds_vis = (uint32_t *)(lds_sph + (TILED ? (uint32_t)RT_TILE_SPHERES : S.nSph));
+    float *lds_eye = (float *)lds; /* RT_EYE_STASH_FLOATS, ahead of the scene data */
+    float4 *lds_poly = lds + RT_EYE_STASH_FLOATS / 4u;
+    float4 *lds_sph = lds_poly + S.nPolySlots;
+    uint32_t *lds_vis = (uint32_t *)(lds_sph + sphere_slots(S.nSph));
 
     /* block b consumes shard b % RT_SHARDS, as slice b / RT_SHARDS of gridDim.x / RT_SHARDS */
     const uint32_t shard = blockIdx.x % RT_SHARDS;
@@ -1122,10 +1159,13 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_bounce(DevScene S, DevCamera C,
     if (slice * RT_BLOCK >= n)
         return; /* block-uniform */
 
-    const float4 *tab = stage_tables(S, lds_vis);
+    const Tables<TABLDS> tab = stage_tables<TABLDS>(S, lds_vis);
     block_copy(lds_poly, S.poly, S.nPolySlots);
-    if (!TILED)
+    if (!TILED) {
         block_copy(lds_sph, S.sph, S.nSph);
+        for (uint32_t k = threadIdx.x; k < S.nSph; k += RT_BLOCK)
+            ((uint32_t *)(lds_sph + S.nSph))[k] = S.sph_obj[k];
+    }
     __syncthreads();
 
     /* first node index of this level in this shard = nodes made by all shallower levels */
@@ -1137,7 +1177,6 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_bounce(DevScene S, DevCamera C,
     const uint32_t node_room = Wk.capS - used;
     const uint32_t qbase = shard * Wk.capS;
 
-    const uint32_t q = level & 1u;
     SpawnCounts sc;
     Tally<STATS> tl;
     PhaseClock pc;
@@ -1148,12 +1187,19 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_bounce(DevScene S, DevCamera C,
      * would also sit out the write latency of every store issued before it: measured, entry load
      * and store drain were 64 % of an iteration's ~13k cycles, the trace-and-shade work itself 36 %.
      */
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 na = zero4, nb = zero4;
-    if (slice * RT_BLOCK + threadIdx.x < n) {
-        na = Wk.qA[q][qbase + slice * RT_BLOCK + threadIdx.x];
-        nb = Wk.qB[q][qbase + slice * RT_BLOCK + threadIdx.x];
+    const float4 *const inA = (level & 1u) ? Wk.qA[1] : Wk.qA[0]; /* selects, not indexing: see shade_and_spawn */
+    const float4 *const inB = (level & 1u) ? Wk.qB[1] : Wk.qB[0];
+    /* (loads are unconditional, on an index clamped into the shard's entries: a load under a branch
+     * makes the compiler merge old and new values and wait right behind the load) */
+    float4 na, nb;
+    {
+        const uint32_t first = min(slice * RT_BLOCK + threadIdx.x, n - 1u);
+        na = inA[qbase + first];
+        nb = inB[qbase + first];
     }
+#define RT_LANDED(u, v) \
+    asm volatile("" : "+v"(u.x), "+v"(u.y), "+v"(u.z), "+v"(u.w), "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w))
+    RT_LANDED(na, nb);
     for (uint32_t base = slice * RT_BLOCK; base < n; base += nslices * RT_BLOCK) {
         const uint32_t i = base + threadIdx.x;
         const bool active = i < n;
@@ -1162,11 +1208,9 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_bounce(DevScene S, DevCamera C,
         uint32_t parent = 0;
         const float4 a = na, b = nb;
         {
-            const uint32_t inext = i + nslices * RT_BLOCK;
-            if (inext < n) {
-                na = Wk.qA[q][qbase + inext];
-                nb = Wk.qB[q][qbase + inext];
-            }
+            const uint32_t inext = min(i + nslices * RT_BLOCK, n - 1u);
+            na = inA[qbase + inext];
+            nb = inB[qbase + inext];
         }
         if (active) {
             r.ox = a.x; r.oy = a.y; r.oz = a.z; r.mag = a.w;
@@ -1186,20 +1230,19 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_bounce(DevScene S, DevCamera C,
         uint32_t node;
         bool sr, st_;
         const float px = r.ox + r.dx * d, py = r.oy + r.dy * d, pz = r.oz + r.dz * d;
-        const uint32_t qi = qbase + (active ? i : 0u);
-        const QueuedEye eye_src{&Wk.qA[q][qi], &Wk.qB[q][qi]};
-        const bool deferred = shade_and_spawn<TILED, STATS>(S, C, Wk, lds_poly, lds_sph, lds_vis, tab, hit, eye_src,
+        StashedEye::park(lds_eye, r);
+        const StashedEye eye_src{lds_eye};
+        const bool deferred = shade_and_spawn<TILED, STATS, TABLDS>(S, C, Wk, lds_poly, lds_sph, lds_vis, tab, hit, eye_src,
                                                             px, py, pz, obj, level,
                                                             ((parent >> 1) << 3) | (parent & 1u), shard, node_base,
                                                             node_room, leaf, node, sr, st_, tl, pc);
         sc.add(hit, sr, st_);
-        asm volatile("" : "+v"(na.x), "+v"(na.y), "+v"(na.z), "+v"(na.w), "+v"(nb.x), "+v"(nb.y), "+v"(nb.z),
-                          "+v"(nb.w)); /* next entry has landed */
+        RT_LANDED(na, nb); /* next entry has landed */
         if (active && !deferred && (parent >> 1) < Wk.cap) {
             /* finished child colour goes straight into the parent's slot */
             const uint32_t pn = parent >> 1;
-            float *dst = (float *)((parent & 1u) ? &Wk.nodeC[pn] : &Wk.nodeB[pn]);
-            dst[0] = leaf[0]; dst[1] = leaf[1]; dst[2] = leaf[2];
+            float4 *dst = (parent & 1u) ? Wk.childT : Wk.childR;
+            dst[pn] = make_float4(leaf[0], leaf[1], leaf[2], 0.0f);
         }
         pc.mark(7);
     }
@@ -1212,14 +1255,22 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_bounce(DevScene S, DevCamera C,
 }
 
 /* colour of a tree node once both children are known: raytrace.c:440-442, 547-549, 562 */
-__device__ __forceinline__ void fold_node(const float4 A, const float4 B, const float4 Cc,
-                                          float out[3])
+__device__ __forceinline__ uint32_t fold_node(const DevWork &Wk, uint32_t i, float out[3])
 {
-    const uint32_t link = __float_as_uint(Cc.w);
+    const float4 A = Wk.nodeA[i];
+    const float2 K = Wk.nodeK[i];
+    const uint32_t link = __float_as_uint(K.y);
     float r = A.x, g = A.y, b = A.z;
-    if (link & 2u) { r += A.w * B.x; g += A.w * B.y; b += A.w * B.z; }
-    if (link & 4u) { r += B.w * Cc.x; g += B.w * Cc.y; b += B.w * Cc.z; }
+    if (link & 2u) {
+        const float4 c = Wk.childR[i];
+        r += A.w * c.x; g += A.w * c.y; b += A.w * c.z;
+    }
+    if (link & 4u) {
+        const float4 c = Wk.childT[i];
+        r += K.x * c.x; g += K.x * c.y; b += K.x * c.z;
+    }
     out[0] = clamp1(r); out[1] = clamp1(g); out[2] = clamp1(b);
+    return link;
 }
 
 /* k_fold: nodes of `level` (>= 1) -> their parent's child slot */
@@ -1237,15 +1288,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_fold(DevWork Wk, uint32_t level)
     const uint32_t start = shard * Wk.capS + used;
     const uint32_t end = start + min((uint32_t)*level_line(cnt, level, shard), Wk.capS - used);
     for (uint32_t i = start + slice * RT_BLOCK + threadIdx.x; i < end; i += nslices * RT_BLOCK) {
-        const float4 A = Wk.nodeA[i], B = Wk.nodeB[i], Cc = Wk.nodeC[i];
         float c[3];
-        fold_node(A, B, Cc, c);
-        const uint32_t link = __float_as_uint(Cc.w);
+        const uint32_t link = fold_node(Wk, i, c);
         const uint32_t pn = link >> 3;
         if (pn >= Wk.cap)
             continue;
-        float *dst = (float *)((link & 1u) ? &Wk.nodeC[pn] : &Wk.nodeB[pn]);
-        dst[0] = c[0]; dst[1] = c[1]; dst[2] = c[2];
+        float4 *dst = (link & 1u) ? Wk.childT : Wk.childR;
+        dst[pn] = make_float4(c[0], c[1], c[2], 0.0f);
     }
 }
 
@@ -1265,11 +1314,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DevCamera C, DevWork Wk, D
         float r = acc.x, g = acc.y, b = acc.z;
         uint32_t root = __float_as_uint(acc.w);
         while (root < Wk.cap) { /* RT_LINK_NONE ends the chain */
-            const float4 A = Wk.nodeA[root], B = Wk.nodeB[root], Cc = Wk.nodeC[root];
             float c[3];
-            fold_node(A, B, Cc, c);
+            const uint32_t link = fold_node(Wk, root, c);
             r = r + c[0]; g = g + c[1]; b = b + c[2];
-            root = __float_as_uint(Cc.w) >> 3;
+            root = link >> 3;
         }
         r = r * C.scale; g = g * C.scale; b = b * C.scale;
         const size_t o = (size_t)R.out_first * C.W + p;
@@ -1311,7 +1359,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_selftest_arith(const float *a, con
 
 size_t rt_scene_lds_bytes(const DevScene &S)
 {
-    const uint32_t sph = S.nSph < RT_TILE_SPHERES ? S.nSph : RT_TILE_SPHERES;
+    const uint32_t sph = sphere_slots(S.nSph);
     /* + one visibility word per thread for every full group of 32 lights before the last group,
      * + the light / object tables when they are staged */
     return (size_t)(S.nPolySlots + sph) * sizeof(float4) + (size_t)vis_words(S.nLights) * sizeof(uint32_t) +
@@ -1324,13 +1372,12 @@ void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk,
     const dim3 grid((C.W + 31u) / 32u, R.ntiles);
     const size_t lds = rt_scene_lds_bytes(S);
     const bool tiled = S.nSph > RT_TILE_SPHERES;
-    if (tiled) {
-        if (stats) k_primary<true, true><<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, R);
-        else       k_primary<true, false><<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, R);
-    } else {
-        if (stats) k_primary<false, true><<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, R);
-        else       k_primary<false, false><<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, R);
-    }
+    /* three scene classes: small (everything in LDS), mid (spheres in LDS, tables in HBM), tiled */
+    void (*kernel)(DevScene, DevCamera, DevWork, DevRows) =
+        tiled ? (stats ? k_primary<true, true, false> : k_primary<true, false, false>)
+        : S.tabInLds ? (stats ? k_primary<false, true, true> : k_primary<false, false, true>)
+                     : (stats ? k_primary<false, true, false> : k_primary<false, false, false>);
+    kernel<<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, R);
 }
 
 /*
@@ -1372,11 +1419,12 @@ static uint32_t queue_grid(const DevWork &Wk, const void *kernel, size_t lds)
 void rt_launch_bounce(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t level,
                       bool stats, hipStream_t stream)
 {
-    const size_t lds = rt_scene_lds_bytes(S);
+    const size_t lds = rt_scene_lds_bytes(S) + RT_EYE_STASH_FLOATS * sizeof(float);
     const bool tiled = S.nSph > RT_TILE_SPHERES;
     void (*kernel)(DevScene, DevCamera, DevWork, uint32_t) =
-        tiled ? (stats ? k_bounce<true, true> : k_bounce<true, false>)
-              : (stats ? k_bounce<false, true> : k_bounce<false, false>);
+        tiled ? (stats ? k_bounce<true, true, false> : k_bounce<true, false, false>)
+        : S.tabInLds ? (stats ? k_bounce<false, true, true> : k_bounce<false, false, true>)
+                     : (stats ? k_bounce<false, true, false> : k_bounce<false, false, false>);
     const uint32_t grid = queue_grid(Wk, (const void *)kernel, lds);
     kernel<<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, level);
 }
