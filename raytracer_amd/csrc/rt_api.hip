@@ -85,6 +85,9 @@ struct rt_hip_ctx {
     bool timing = false;
     uint64_t batch_samples = 0;
     std::vector<hipEvent_t> ev; /* 2 per batch when timing */
+    hipEvent_t round_done = nullptr; /* recorded behind each round's counter copy: drain() waits for
+                                        THIS context's work only, so two contexts can alternate
+                                        on one stream and hide each other's host latency */
     size_t cwords = RT_COUNTER_WORDS; /* counter words in use per batch (depends on depth) */
     rt_hip_stats stats{};
 };
@@ -261,10 +264,14 @@ int enqueue_round(rt_hip_ctx *c)
             return rc;
         c->batches.push_back(b);
     }
-    if (!c->batches.empty())
+    if (!c->batches.empty()) {
         HIP_TRY(hipMemcpyAsync(c->h_counters, c->d_counters,
                                c->batches.size() * c->cwords * sizeof(uint32_t), hipMemcpyDeviceToHost,
                                c->stream));
+        if (!c->round_done)
+            HIP_TRY(hipEventCreateWithFlags(&c->round_done, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c->round_done, c->stream));
+    }
     return 0;
 }
 
@@ -273,7 +280,10 @@ int enqueue_round(rt_hip_ctx *c)
 int drain(rt_hip_ctx *c)
 {
     for (;;) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->round_done && !c->batches.empty())
+            HIP_TRY(hipEventSynchronize(c->round_done));
+        else
+            HIP_TRY(hipStreamSynchronize(c->stream));
         for (size_t i = 0; i < c->batches.size(); ++i) {
             const Batch &b = c->batches[i];
             const uint32_t *cnt = c->h_counters + i * c->cwords;
@@ -451,6 +461,7 @@ void rt_hip_ctx_destroy(rt_hip_ctx *c)
     if (c->pending)
         (void)hipStreamSynchronize(c->stream);
     drop_events(c);
+    if (c->round_done) (void)hipEventDestroy(c->round_done);
     if (c->scene_blob) (void)hipFree(c->scene_blob);
     if (c->work_blob) (void)hipFree(c->work_blob);
     if (c->pixAcc) (void)hipFree(c->pixAcc);
