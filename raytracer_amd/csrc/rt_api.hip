@@ -68,6 +68,8 @@ struct rt_hip_ctx {
     DevWork W{};
     float4 *pixAcc = nullptr;
     size_t pix_cap = 0;
+    uint32_t *roots = nullptr; /* [spp^2][pixels of a batch] */
+    size_t roots_cap = 0;
     uint32_t *d_counters = nullptr; /* [kMaxBatches][RT_COUNTER_WORDS] */
     uint32_t *h_counters = nullptr; /* pinned mirror */
     /* pending render */
@@ -127,16 +129,24 @@ void fold_camera(DevCamera &C, const rt_camera &cam)
     C.depth = cam.depth;
 }
 
-int ensure_pix(rt_hip_ctx *c, size_t npix)
+int ensure_pix(rt_hip_ctx *c, size_t npix, size_t spp2)
 {
-    if (npix <= c->pix_cap)
-        return 0;
-    if (c->pixAcc)
-        HIP_TRY(hipFree(c->pixAcc));
-    c->pixAcc = nullptr;
-    c->pix_cap = 0;
-    HIP_TRY(hipMalloc((void **)&c->pixAcc, npix * sizeof(float4)));
-    c->pix_cap = npix;
+    if (npix > c->pix_cap) {
+        if (c->pixAcc)
+            HIP_TRY(hipFree(c->pixAcc));
+        c->pixAcc = nullptr;
+        c->pix_cap = 0;
+        HIP_TRY(hipMalloc((void **)&c->pixAcc, npix * sizeof(float4)));
+        c->pix_cap = npix;
+    }
+    if (npix * spp2 > c->roots_cap) {
+        if (c->roots)
+            HIP_TRY(hipFree(c->roots));
+        c->roots = nullptr;
+        c->roots_cap = 0;
+        HIP_TRY(hipMalloc((void **)&c->roots, npix * spp2 * sizeof(uint32_t)));
+        c->roots_cap = npix * spp2;
+    }
     return 0;
 }
 
@@ -164,6 +174,7 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
     const DevRows R = rows_of(c, b);
     DevWork Wk = c->W;
     Wk.pixAcc = c->pixAcc;
+    Wk.roots = c->roots;
     Wk.counters = c->d_counters + (size_t)b.slot * c->cwords;
     hipStream_t st = c->stream;
     HIP_TRY(hipMemsetAsync(Wk.counters, 0, c->cwords * sizeof(uint32_t), st));
@@ -465,6 +476,7 @@ void rt_hip_ctx_destroy(rt_hip_ctx *c)
     if (c->scene_blob) (void)hipFree(c->scene_blob);
     if (c->work_blob) (void)hipFree(c->work_blob);
     if (c->pixAcc) (void)hipFree(c->pixAcc);
+    if (c->roots) (void)hipFree(c->roots);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     delete c;
@@ -634,7 +646,7 @@ static int submit(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb, float *
         return 0;
     const uint32_t per = tiles_per_batch(c, default_batch_samples(c));
     const uint32_t most = per < job.ntiles ? per : job.ntiles;
-    rc = ensure_pix(c, (size_t)most * 8u * c->C.W);
+    rc = ensure_pix(c, (size_t)most * 8u * c->C.W, (size_t)c->C.sqrtSpp * c->C.sqrtSpp);
     if (rc)
         return rc;
     for (uint32_t t = job.ntiles; t > 0;) { /* pushed back to front: the list is popped from the end */

@@ -82,7 +82,10 @@ struct DevWork {
     float4 *childT;       /* (transmission child rgb, -) consecutive rays have consecutive parents,
                              so a wave's results are full-line stores (12-byte pieces of a shared
                              float4 made every store a partial-sector read-modify-write)          */
-    float4 *pixAcc;       /* per pixel of the batch: (immediate sum rgb, bits head)    */
+    float4 *pixAcc;       /* per pixel of the batch: (immediate sum rgb, bits #roots)  */
+    uint32_t *roots;      /* [spp^2][pixels of the batch] k-th root node of a pixel: the roots of
+                             a pixel are independent loads for k_resolve (a linked chain through
+                             the nodes cost one dependent HBM round trip per sample)   */
     uint32_t *counters;   /* counter block of this batch (layout below)                */
     uint32_t cap;         /* entries per queue / node pool                             */
     uint32_t capS;        /* entries per shard = cap / RT_SHARDS                       */

@@ -1092,7 +1092,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_primary(DevScene S, DevCam
     const uint32_t node_base = shard * Wk.capS; /* level 0 opens every shard's node range */
 
     float accr = 0.0f, accg = 0.0f, accb = 0.0f; /* color_init raytrace.c:908 */
-    uint32_t head = RT_LINK_NONE;
+    uint32_t nroots = 0; /* samples of this pixel that became tree roots */
+    const size_t pix = (size_t)(blockIdx.y * 8u + (lane >> 3)) * C.W + x; /* pixel of the batch */
+    const size_t pix_stride = (size_t)R.ntiles * 8u * C.W;
     SpawnCounts sc;
     Tally<STATS> tl;
     PhaseClock pc; /* unused here */
@@ -1113,11 +1115,12 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_primary(DevScene S, DevCam
             const float px = r.ox + r.dx * d, py = r.oy + r.dy * d, pz = r.oz + r.dz * d;
             const PrimaryEye eye_src{C, fu0, fv0, i, j};
             const bool deferred = shade_and_spawn<TILED, STATS, TABLDS>(S, C, Wk, lds_poly, lds_sph, lds_vis, tab, hit,
-                                                                eye_src, px, py, pz, obj, 0u, head << 3, shard,
+                                                                eye_src, px, py, pz, obj, 0u, RT_LINK_NONE << 3, shard,
                                                                 node_base, Wk.capS, leaf, node, sr, st_, tl, pc);
             sc.add(hit, sr, st_);
             if (deferred) {
-                head = node; /* resolved later; chain of this pixel's roots */
+                Wk.roots[(size_t)nroots * pix_stride + pix] = node; /* resolved by k_resolve */
+                ++nroots;
             } else {
                 accr = accr + leaf[0]; /* color_add raytrace.c:774 */
                 accg = accg + leaf[1];
@@ -1126,8 +1129,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_primary(DevScene S, DevCam
         }
     }
     if (valid)
-        Wk.pixAcc[(size_t)(blockIdx.y * 8u + (lane >> 3)) * C.W + x] =
-            make_float4(accr, accg, accb, __uint_as_float(head));
+        Wk.pixAcc[pix] = make_float4(accr, accg, accb, __uint_as_float(nroots));
 
     uint64_t *st = (uint64_t *)(Wk.counters + CNT_STATS + shard * CNT_STATS_STRIDE);
     wave_add_total(st, ST_K0_SHADE_NODES, sc.shade_nodes);
@@ -1255,22 +1257,20 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_bounce(DevScene S, DevCamera C,
 }
 
 /* colour of a tree node once both children are known: raytrace.c:440-442, 547-549, 562 */
-__device__ __forceinline__ uint32_t fold_node(const DevWork &Wk, uint32_t i, float out[3])
+__device__ __forceinline__ uint32_t fold_values(const float4 A, const float2 K, const float4 cr,
+                                                const float4 ct, float out[3])
 {
-    const float4 A = Wk.nodeA[i];
-    const float2 K = Wk.nodeK[i];
     const uint32_t link = __float_as_uint(K.y);
     float r = A.x, g = A.y, b = A.z;
-    if (link & 2u) {
-        const float4 c = Wk.childR[i];
-        r += A.w * c.x; g += A.w * c.y; b += A.w * c.z;
-    }
-    if (link & 4u) {
-        const float4 c = Wk.childT[i];
-        r += K.x * c.x; g += K.x * c.y; b += K.x * c.z;
-    }
+    if (link & 2u) { r += A.w * cr.x; g += A.w * cr.y; b += A.w * cr.z; }
+    if (link & 4u) { r += K.x * ct.x; g += K.x * ct.y; b += K.x * ct.z; }
     out[0] = clamp1(r); out[1] = clamp1(g); out[2] = clamp1(b);
     return link;
+}
+/* all four loads are issued together (the child slots unconditionally: one round trip, not two) */
+__device__ __forceinline__ uint32_t fold_node(const DevWork &Wk, uint32_t i, float out[3])
+{
+    return fold_values(Wk.nodeA[i], Wk.nodeK[i], Wk.childR[i], Wk.childT[i], out);
 }
 
 /* k_fold: nodes of `level` (>= 1) -> their parent's child slot */
@@ -1312,12 +1312,28 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DevCamera C, DevWork Wk, D
             continue; /* the last tile row of a slab may hang over its end */
         const float4 acc = Wk.pixAcc[p];
         float r = acc.x, g = acc.y, b = acc.z;
-        uint32_t root = __float_as_uint(acc.w);
-        while (root < Wk.cap) { /* RT_LINK_NONE ends the chain */
-            float c[3];
-            const uint32_t link = fold_node(Wk, root, c);
-            r = r + c[0]; g = g + c[1]; b = b + c[2];
-            root = link >> 3;
+        const uint32_t nroots = __float_as_uint(acc.w);
+        /* four roots at a time: ids first, then all their node words, then the sums in root order */
+        for (uint32_t k = 0; k < nroots; k += 4u) {
+            uint32_t id[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u)
+                id[u] = Wk.roots[(size_t)min(k + u, nroots - 1u) * npix + p];
+            float4 A[4], cr[4], ct[4];
+            float2 K[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) {
+                const uint32_t j = id[u] < Wk.cap ? id[u] : 0u;
+                A[u] = Wk.nodeA[j]; K[u] = Wk.nodeK[j]; cr[u] = Wk.childR[j]; ct[u] = Wk.childT[j];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) {
+                if (k + u < nroots && id[u] < Wk.cap) {
+                    float c[3];
+                    fold_values(A[u], K[u], cr[u], ct[u], c);
+                    r = r + c[0]; g = g + c[1]; b = b + c[2];
+                }
+            }
         }
         r = r * C.scale; g = g * C.scale; b = b * C.scale;
         const size_t o = (size_t)R.out_first * C.W + p;
