@@ -262,6 +262,11 @@ int  rt_scene_synthetic(rt_scene_t *scene, uint64_t seed, uint32_t nSpheres,
  * + RGB bytes, row 0 first.  Returns 1 on success, 0 on failure. */
 int  rt_write_image(const char *filename, const unsigned int *buffer,
                     unsigned int width, unsigned int height);
+/* The same writer under the reference's own name and prototype (output.h:15-16), so that the
+ * reference's main.c links against this library alone when libnetpbm / GLUT are not installed.
+ * A host that links its own output.o keeps its own definition (executable symbols win). */
+int  write_image(const char *filename, unsigned int *buffer,
+                 unsigned int width, unsigned int height);
 
 #ifdef __cplusplus
 } /* extern "C" */

@@ -15,7 +15,7 @@ EXPORTS = [
     "rt_hip_scene_upload", "rt_hip_render_rows", "rt_hip_render_interleaved", "rt_hip_finish", "rt_hip_render_stats",
     "rt_hip_ctx_set_timing", "rt_hip_ctx_set_batch_samples", "rt_hip_last_error", "rt_hip_version",
     "rt_poly_plane", "rt_scene_builtin", "rt_parse_scene", "rt_scene_free", "rt_scene_synthetic",
-    "rt_write_image", "rt_hip_selftest_arith",
+    "rt_write_image", "write_image", "rt_hip_selftest_arith",
 ]
 
 _lib = None
@@ -76,6 +76,8 @@ def load():
     lib.rt_scene_synthetic.restype = i32
     lib.rt_write_image.argtypes = [C.c_char_p, vp, C.c_uint, C.c_uint]
     lib.rt_write_image.restype = i32
+    lib.write_image.argtypes = [C.c_char_p, vp, C.c_uint, C.c_uint]
+    lib.write_image.restype = i32
     _lib = lib
     return lib
 

@@ -346,3 +346,9 @@ int rt_write_image(const char *filename, const unsigned int *buffer, unsigned in
     fclose(fp);
     return ok;
 }
+
+/* output.h:15-16 */
+int write_image(const char *filename, unsigned int *buffer, unsigned int width, unsigned int height)
+{
+    return rt_write_image(filename, buffer, width, height);
+}

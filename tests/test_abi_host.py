@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_functions():
     src = open(os.path.join(ROOT, "include", "rt_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(rt_[a-z_0-9]+|raytrace)\s*\(", src)) - {"rt_hip_ctx"})
+    return sorted(set(re.findall(r"\b(rt_[a-z_0-9]+|raytrace|write_image)\s*\(", src)) - {"rt_hip_ctx"})
 
 
 def test_every_declared_symbol_is_exported_and_bound():

@@ -399,3 +399,33 @@ def test_arith_helpers_are_ieee(torch_cuda):
         pos = np.isfinite(a) & (a > 0)
         want64 = np.sqrt(a.astype(np.float64))
         assert (o64[pos].view(np.uint64) == want64[pos].view(np.uint64)).all()
+
+
+def test_reference_main_links_and_runs_against_the_library(golden, tmp_path):
+    """INTEGRATION.md section 1, end to end: oracle/_ref/rt_dropin is the reference's own main.c + scene.c
+    (+ colour / geometry / vector helpers), compiled from the untouched sources by oracle/Makefile and linked
+    against librt_hip.so in place of raytrace.o, ray.o and output.o.  Run with the reference's argv contract
+    (main.c:96-104) it must write the P6 file the reference writes (libnetpbm's raw PPM bytes)."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "rt_dropin")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/rt_dropin was not built (needs /root/reference at build time)")
+    _, arrays = golden
+    scene_file = tmp_path / "scene"
+    scene_file.write_text("# parse_scene only needs a readable file (scene.c:31-35); it ignores the contents\n")
+    out = tmp_path / "out.ppm"
+    p = subprocess.run([exe, str(out), str(scene_file), "640", "480", "1", "4"], capture_output=True, text=True,
+                       timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "Running Ray Tracer..." in p.stdout and "Run time:" in p.stdout      # main.c:144,170
+    data = out.read_bytes()
+    head = b"P6\n640 480\n255\n"
+    assert data.startswith(head) and len(data) == len(head) + 640 * 480 * 3
+    got = np.frombuffer(data[len(head):], np.uint8).reshape(480, 640, 3).astype(int)
+    want = rgb_bytes(arrays["builtin_640x480_s1_d4_argb"]).reshape(480, 640, 3)
+    assert (np.abs(got - want).max(-1) <= 1).mean() >= LSB_FRAC
+    assert (got == want).all(-1).mean() > 0.9999
+    # usage message and exit status of a short command line (main.c:127-131)
+    q = subprocess.run([exe, str(out)], capture_output=True, text=True, timeout=60)
+    assert q.returncode == 1 and "raytrace outputFile sceneFile imgWidth imgHeight" in q.stdout
