@@ -436,16 +436,16 @@ int rt_hip_ctx_create(rt_hip_ctx **out, int device, uint64_t max_queue_rays)
         delete c;
         return rc;
     }
-    /* one blob: 4 queue arrays + 3 node arrays of cap float4 each + one of cap float2 */
+    /* one blob: 6 queue arrays + 3 node arrays of cap float4 each + one of cap float2 */
     const size_t arr = align_up(cap * sizeof(float4), 256);
-    hipError_t e = hipMalloc(&c->work_blob, arr * 7 + arr / 2);
+    hipError_t e = hipMalloc(&c->work_blob, arr * 9 + arr / 2);
     if (e == hipSuccess)
         e = hipMalloc((void **)&c->d_counters, (size_t)kMaxBatches * RT_COUNTER_WORDS * sizeof(uint32_t));
     if (e == hipSuccess)
         e = hipHostMalloc((void **)&c->h_counters, (size_t)kMaxBatches * RT_COUNTER_WORDS * sizeof(uint32_t),
                           hipHostMallocDefault);
     if (e != hipSuccess) {
-        set_err("allocating %zu bytes of queue memory failed: %s", arr * 7 + arr / 2, hipGetErrorString(e));
+        set_err("allocating %zu bytes of queue memory failed: %s", arr * 9 + arr / 2, hipGetErrorString(e));
         rt_hip_ctx_destroy(c);
         return -(int)e;
     }
@@ -454,10 +454,12 @@ int rt_hip_ctx_create(rt_hip_ctx **out, int device, uint64_t max_queue_rays)
     c->W.qB[0] = (float4 *)(p + 1 * arr);
     c->W.qA[1] = (float4 *)(p + 2 * arr);
     c->W.qB[1] = (float4 *)(p + 3 * arr);
-    c->W.nodeA = (float4 *)(p + 4 * arr);
-    c->W.childR = (float4 *)(p + 5 * arr);
-    c->W.childT = (float4 *)(p + 6 * arr);
-    c->W.nodeK = (float2 *)(p + 7 * arr); /* half an array */
+    c->W.qC[0] = (float4 *)(p + 4 * arr);
+    c->W.qC[1] = (float4 *)(p + 5 * arr);
+    c->W.nodeA = (float4 *)(p + 6 * arr);
+    c->W.childR = (float4 *)(p + 7 * arr);
+    c->W.childT = (float4 *)(p + 8 * arr);
+    c->W.nodeK = (float2 *)(p + 9 * arr); /* half an array */
     c->W.cap = (uint32_t)cap;
     c->W.capS = (uint32_t)(cap / RT_SHARDS);
     *out = c;

@@ -74,8 +74,9 @@ struct DevRows {
 
 /* Per-batch work state in HBM. */
 struct DevWork {
-    float4 *qA[2];        /* ray queues, ping-pong by level parity: (ox,oy,oz,magnitude) */
-    float4 *qB[2];        /*                                         (dx,dy,dz,bits parent<<1|slot) */
+    float4 *qA[2];        /* hit queues, ping-pong by level parity: (hit point, bits object)      */
+    float4 *qB[2];        /*   (origin of the ray that found the hit, bits parent<<1|slot)        */
+    float4 *qC[2];        /*   (direction of that ray, -)                                         */
     float4 *nodeA;        /* (local rgb, kr)                        written when the node is made */
     float2 *nodeK;        /* (kt, bits link)                        written when the node is made */
     float4 *childR;       /* (reflection child rgb, -)   written by the child, as a whole float4:  */

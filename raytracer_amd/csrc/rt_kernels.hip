@@ -830,8 +830,8 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
         }
     }
     pc.mark(3);
-    if (!hit)
-        return false;
+    if (!TILED && !hit)
+        return false; /* (tiled: every thread must reach the child searches below - block barriers) */
 
     /* material, object colour, normal and view vector for the combine and the spawn */
     const float4 mA = tab[rec + RT_OBJ_DIFFUSE];
@@ -865,11 +865,11 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     outb += (mC.x * dfb) * ocb + (mB.w * spb) * mB.z;
 
     const float kr = mC.z, kt = mC.w;
-    const bool want_r = (kr != 0.0f) && (level != C.depth); /* raytrace.c:405 */
-    const bool want_t = (kt != 0.0f) && (level != C.depth); /* raytrace.c:452 */
+    const bool want_r = hit && (kr != 0.0f) && (level != C.depth); /* raytrace.c:405 */
+    const bool want_t = hit && (kt != 0.0f) && (level != C.depth); /* raytrace.c:452 */
     spawn_r = want_r;
     spawn_t = want_t;
-    if (!(want_r || want_t)) {
+    if (!TILED && !(want_r || want_t)) {
         leaf[0] = clamp1(outr); /* raytrace.c:562 */
         leaf[1] = clamp1(outg);
         leaf[2] = clamp1(outb);
@@ -891,11 +891,95 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     float Vx = eox - px, Vy = eoy - py, Vz = eoz - pz;
     normalize3(Vx, Vy, Vz);
 
+    /*
+     * The child rays are traced HERE, by the lane that spawns them (get_ray_color's closest-hit
+     * search, raytrace.c:231-272, of the recursive calls at :427 and :539): a child that hits
+     * nothing contributes the background colour at once (raytrace.c:446,509,553) and never touches
+     * HBM - 71 % of the level-1 rays of the Whitted scene - and a node is made only when a child
+     * did hit something.  The queues carry hits (point, object, the ray that found it), so the
+     * consumer starts at the shading.
+     */
+    Ray cr; /* the child ray being traced */
+    bool hit_r = false, hit_t = false;
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0; /* reflection child's queue entry */
+    float4 t0 = r0, t1 = r0, t2 = r0;                              /* transmission child's        */
+#pragma unroll 1
+    for (uint32_t child = 0; child < 2u; ++child) {
+        const bool want = child ? want_t : want_r;
+        if (child == 0u) {
+            if (want) { /* reflection ray raytrace.c:408-425 */
+                const float t2x = 2.0f * dot3(Vx, Vy, Vz, Nx, Ny, Nz);
+                cr.ox = px; cr.oy = py; cr.oz = pz;
+                cr.dx = Nx * t2x - Vx; cr.dy = Ny * t2x - Vy; cr.dz = Nz * t2x - Vz;
+                cr.mag = 9999999.9f;
+                tinypush(cr);
+            }
+        } else {
+            if (want) { /* transmission ray raytrace.c:455-537 */
+                float nit = 1.0f / mD.x;
+                float edx, edy, edz;
+                eye_src.direction(edx, edy, edz);
+                const float Tx = edx * nit, Ty = edy * nit, Tz = edz * nit;
+                const float cs = dot3(Vx, Vy, Vz, Nx, Ny, Nz);
+                float Fx = Nx, Fy = Ny, Fz = Nz;
+                if (cs < 0.0f) { /* inside the object moving out */
+                    nit = 1.0f / nit;
+                    Fx = Nx * -1.0f; Fy = Ny * -1.0f; Fz = Nz * -1.0f;
+                }
+                const float det = 1.0f + (nit * nit) * (cs * cs - 1.0f);
+                cr.ox = px; cr.oy = py; cr.oz = pz;
+                if (det < 0.0f) { /* total internal reflection :470-489 */
+                    const float t2x = 2.0f * dot3(Vx, Vy, Vz, Fx, Fy, Fz);
+                    cr.dx = Fx * t2x - Vx; cr.dy = Fy * t2x - Vy; cr.dz = Fz * t2x - Vz;
+                    cr.mag = 999999.0f;
+                } else { /* :517-525: 1/n (not nit) times cos, minus a double sqrt */
+                    const float k = (float)((double)((1.0f / mD.x) * cs) - sqrt((double)det));
+                    cr.dx = Tx + Fx * k; cr.dy = Ty + Fy * k; cr.dz = Tz + Fz * k;
+                    cr.mag = 99999.9f;
+                }
+                tinypush(cr);
+            }
+        }
+        if (!want) {
+            cr.ox = cr.oy = cr.oz = cr.dx = cr.dy = cr.dz = cr.mag = 0.0f;
+        }
+        float cd;
+        uint32_t cobj;
+        intersect_all<TILED, true, false, STATS>(S, lds_poly, lds_sph, want, cr, RT_NONE, RT_NONE, cd, cobj, tl);
+        const bool chit = want && (cobj != RT_NONE);
+        /* the child's hit point, as its get_ray_color would form it (ray.c:121-122, 236-237) */
+        const float4 e0 = make_float4(cr.ox + cr.dx * cd, cr.oy + cr.dy * cd, cr.oz + cr.dz * cd,
+                                      __uint_as_float(cobj));
+        if (child == 0u) {
+            hit_r = chit;
+            r0 = e0;
+            r1 = make_float4(cr.ox, cr.oy, cr.oz, 0.f);
+            r2 = make_float4(cr.dx, cr.dy, cr.dz, 0.f);
+        } else {
+            hit_t = chit;
+            t0 = e0;
+            t1 = make_float4(cr.ox, cr.oy, cr.oz, 0.f);
+            t2 = make_float4(cr.dx, cr.dy, cr.dz, 0.f);
+        }
+    }
+    if (!hit)
+        return false;
+    if (!(hit_r || hit_t)) {
+        /* every child (if any) left the scene: the node is finished.  Same expression order as
+         * fold_values: local + kr*child, then + kt*child, then the clamp (raytrace.c:440-442,547-549,562) */
+        if (want_r) { outr += kr * S.bg[0]; outg += kr * S.bg[1]; outb += kr * S.bg[2]; }
+        if (want_t) { outr += kt * S.bg[0]; outg += kt * S.bg[1]; outb += kt * S.bg[2]; }
+        leaf[0] = clamp1(outr);
+        leaf[1] = clamp1(outg);
+        leaf[2] = clamp1(outb);
+        return false;
+    }
+
     pc.mark(4);
-    /* tree node + child rays: one reservation per wave */
+    /* tree node + queue slots for the children that hit: one reservation per wave */
     uint32_t *cnt = Wk.counters;
     uint32_t local, slot_r, slot_t;
-    wave_reserve(level_line(cnt, level, shard), want_r, want_t, node_room, Wk.capS, &cnt[CNT_OVERFLOW + level],
+    wave_reserve(level_line(cnt, level, shard), hit_r, hit_t, node_room, Wk.capS, &cnt[CNT_OVERFLOW + level],
                  local, slot_r, slot_t);
     pc.mark(5);
     if (local == RT_NONE) { /* overflow: the batch will be re-rendered in smaller pieces */
@@ -906,56 +990,30 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     node_idx = node;
     Wk.nodeA[node] = make_float4(outr, outg, outb, kr);
     Wk.nodeK[node] = make_float2(kt, __uint_as_float(link | (want_r ? 2u : 0u) | (want_t ? 4u : 0u)));
+    const float4 bg4 = make_float4(S.bg[0], S.bg[1], S.bg[2], 0.0f);
+    if (want_r && !hit_r)
+        Wk.childR[node] = bg4;
+    if (want_t && !hit_t)
+        Wk.childT[node] = bg4;
 
     /* queue of the next level: picked with selects - indexing the kernel-argument pointer array
      * with a run-time value makes the compiler re-load the pointer from memory at every use */
     const bool odd_next = ((level + 1) & 1u) != 0;
     float4 *const outA = odd_next ? Wk.qA[1] : Wk.qA[0];
     float4 *const outB = odd_next ? Wk.qB[1] : Wk.qB[0];
+    float4 *const outC = odd_next ? Wk.qC[1] : Wk.qC[0];
     const uint32_t qbase = shard * Wk.capS;
-
-    /* reflection ray raytrace.c:408-425 */
-    Ray rr;
-    if (want_r) {
-        const float t2 = 2.0f * dot3(Vx, Vy, Vz, Nx, Ny, Nz);
-        rr.ox = px; rr.oy = py; rr.oz = pz;
-        rr.dx = Nx * t2 - Vx; rr.dy = Ny * t2 - Vy; rr.dz = Nz * t2 - Vz;
-        rr.mag = 9999999.9f;
-        tinypush(rr);
-    }
     if (slot_r != RT_NONE) {
-        outA[qbase + slot_r] = make_float4(rr.ox, rr.oy, rr.oz, rr.mag);
-        outB[qbase + slot_r] = make_float4(rr.dx, rr.dy, rr.dz, __uint_as_float((node << 1) | 0u));
-    }
-    /* transmission ray raytrace.c:455-537 */
-    Ray tr;
-    if (want_t) {
-        float nit = 1.0f / mD.x;
-        float edx, edy, edz;
-        eye_src.direction(edx, edy, edz);
-        const float Tx = edx * nit, Ty = edy * nit, Tz = edz * nit;
-        const float cs = dot3(Vx, Vy, Vz, Nx, Ny, Nz);
-        float Fx = Nx, Fy = Ny, Fz = Nz;
-        if (cs < 0.0f) { /* inside the object moving out */
-            nit = 1.0f / nit;
-            Fx = Nx * -1.0f; Fy = Ny * -1.0f; Fz = Nz * -1.0f;
-        }
-        const float det = 1.0f + (nit * nit) * (cs * cs - 1.0f);
-        tr.ox = px; tr.oy = py; tr.oz = pz;
-        if (det < 0.0f) { /* total internal reflection :470-489 */
-            const float t2 = 2.0f * dot3(Vx, Vy, Vz, Fx, Fy, Fz);
-            tr.dx = Fx * t2 - Vx; tr.dy = Fy * t2 - Vy; tr.dz = Fz * t2 - Vz;
-            tr.mag = 999999.0f;
-        } else { /* :517-525: 1/n (not nit) times cos, minus a double sqrt */
-            const float k = (float)((double)((1.0f / mD.x) * cs) - sqrt((double)det));
-            tr.dx = Tx + Fx * k; tr.dy = Ty + Fy * k; tr.dz = Tz + Fz * k;
-            tr.mag = 99999.9f;
-        }
-        tinypush(tr);
+        r1.w = __uint_as_float((node << 1) | 0u);
+        outA[qbase + slot_r] = r0;
+        outB[qbase + slot_r] = r1;
+        outC[qbase + slot_r] = r2;
     }
     if (slot_t != RT_NONE) {
-        outA[qbase + slot_t] = make_float4(tr.ox, tr.oy, tr.oz, tr.mag);
-        outB[qbase + slot_t] = make_float4(tr.dx, tr.dy, tr.dz, __uint_as_float((node << 1) | 1u));
+        t1.w = __uint_as_float((node << 1) | 1u);
+        outA[qbase + slot_t] = t0;
+        outB[qbase + slot_t] = t1;
+        outC[qbase + slot_t] = t2;
     }
     pc.mark(6);
     return true;
@@ -1142,7 +1200,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_primary(DevScene S, DevCam
 /* k_bounce: one queued secondary ray per lane (reflection / transmission of level-1 nodes)    */
 /* ------------------------------------------------------------------------------------------ */
 template <bool TILED, bool STATS, bool TABLDS>
-__global__ __launch_bounds__(RT_BLOCK, 6) void k_bounce(DevScene S, DevCamera C, DevWork Wk,
+__global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_bounce(DevScene S, DevCamera C, DevWork Wk,
                                                      uint32_t level)
 {
     extern __shared__ __attribute__((aligned(16))) float4 lds[];
@@ -1191,47 +1249,45 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_bounce(DevScene S, DevCamera C,
      */
     const float4 *const inA = (level & 1u) ? Wk.qA[1] : Wk.qA[0]; /* selects, not indexing: see shade_and_spawn */
     const float4 *const inB = (level & 1u) ? Wk.qB[1] : Wk.qB[0];
+    const float4 *const inC = (level & 1u) ? Wk.qC[1] : Wk.qC[0];
     /* (loads are unconditional, on an index clamped into the shard's entries: a load under a branch
      * makes the compiler merge old and new values and wait right behind the load) */
-    float4 na, nb;
+    float4 na, nb, nc;
     {
         const uint32_t first = min(slice * RT_BLOCK + threadIdx.x, n - 1u);
         na = inA[qbase + first];
         nb = inB[qbase + first];
+        nc = inC[qbase + first];
     }
-#define RT_LANDED(u, v) \
-    asm volatile("" : "+v"(u.x), "+v"(u.y), "+v"(u.z), "+v"(u.w), "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w))
-    RT_LANDED(na, nb);
+#define RT_LANDED(P_, Q_, R_) \
+    asm volatile("" : "+v"(P_.x), "+v"(P_.y), "+v"(P_.z), "+v"(P_.w), "+v"(Q_.x), "+v"(Q_.y), "+v"(Q_.z), \
+                      "+v"(Q_.w), "+v"(R_.x), "+v"(R_.y), "+v"(R_.z))
+    RT_LANDED(na, nb, nc);
     for (uint32_t base = slice * RT_BLOCK; base < n; base += nslices * RT_BLOCK) {
         const uint32_t i = base + threadIdx.x;
         const bool active = i < n;
         pc.start();
-        Ray r;
-        uint32_t parent = 0;
-        const float4 a = na, b = nb;
+        const float4 a = na, b = nb, c = nc;
         {
             const uint32_t inext = min(i + nslices * RT_BLOCK, n - 1u);
             na = inA[qbase + inext];
             nb = inB[qbase + inext];
+            nc = inC[qbase + inext];
         }
-        if (active) {
-            r.ox = a.x; r.oy = a.y; r.oz = a.z; r.mag = a.w;
-            r.dx = b.x; r.dy = b.y; r.dz = b.z;
-            parent = __float_as_uint(b.w);
-        } else {
-            r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.mag = 0.0f;
-        }
+        /* a queued hit: (point, object), (origin of the ray that found it, parent), (its direction) */
+        const float px = a.x, py = a.y, pz = a.z;
+        const uint32_t obj = active ? __float_as_uint(a.w) : 0u;
+        const uint32_t parent = active ? __float_as_uint(b.w) : 0u;
+        Ray r;
+        r.ox = b.x; r.oy = b.y; r.oz = b.z;
+        r.dx = c.x; r.dy = c.y; r.dz = c.z;
+        r.mag = 0.0f;
         pc.mark(0);
-        float d;
-        uint32_t obj;
-        intersect_all<TILED, true, false, STATS>(S, lds_poly, lds_sph, active, r, RT_NONE, RT_NONE, d, obj,
-                                                 tl);
         pc.mark(1);
-        const bool hit = active && (obj != RT_NONE);
-        float leaf[3] = {S.bg[0], S.bg[1], S.bg[2]}; /* miss: kr/kt * bgColor raytrace.c:446,509,553 */
+        const bool hit = active;
+        float leaf[3] = {S.bg[0], S.bg[1], S.bg[2]};
         uint32_t node;
         bool sr, st_;
-        const float px = r.ox + r.dx * d, py = r.oy + r.dy * d, pz = r.oz + r.dz * d;
         StashedEye::park(lds_eye, r);
         const StashedEye eye_src{lds_eye};
         const bool deferred = shade_and_spawn<TILED, STATS, TABLDS>(S, C, Wk, lds_poly, lds_sph, lds_vis, tab, hit, eye_src,
@@ -1239,7 +1295,7 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_bounce(DevScene S, DevCamera C,
                                                             ((parent >> 1) << 3) | (parent & 1u), shard, node_base,
                                                             node_room, leaf, node, sr, st_, tl, pc);
         sc.add(hit, sr, st_);
-        RT_LANDED(na, nb); /* next entry has landed */
+        RT_LANDED(na, nb, nc); /* next entry has landed */
         if (active && !deferred && (parent >> 1) < Wk.cap) {
             /* finished child colour goes straight into the parent's slot */
             const uint32_t pn = parent >> 1;
