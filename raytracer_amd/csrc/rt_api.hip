@@ -605,14 +605,15 @@ int rt_hip_scene_upload(rt_hip_ctx *c, const rt_scene *sc)
     S.tabSlots = (uint32_t)tab.size();
     S.tabInLds = 0;
     S.tabInLds = (nSph <= RT_TILE_SPHERES &&
-                  rt_scene_lds_bytes(S) + tab.size() * sizeof(float4) <= RT_LDS_TABLE_BUDGET) ? 1u : 0u;
+                  rt_scene_lds_bytes(S) - RT_PARK_FLOATS * sizeof(float) + tab.size() * sizeof(float4) <=
+                      RT_LDS_TABLE_BUDGET) ? 1u : 0u;
     S.bg[0] = sc->bgColor.r; S.bg[1] = sc->bgColor.g; S.bg[2] = sc->bgColor.b;
     S.ambient[0] = sc->ambientLightColor.r;
     S.ambient[1] = sc->ambientLightColor.g;
     S.ambient[2] = sc->ambientLightColor.b;
-    if (rt_scene_lds_bytes(S) + 6u * RT_BLOCK * sizeof(float) > 65536u) {
+    if (rt_scene_lds_bytes(S) > 65536u) {
         set_err("scene needs %zu bytes of LDS per block (polygon data, sphere tile, %u lights), limit is 64 KiB",
-                rt_scene_lds_bytes(S) + 6u * RT_BLOCK * sizeof(float), nL);
+                rt_scene_lds_bytes(S), nL);
         return RT_E_INVALID;
     }
     c->have_scene = true;

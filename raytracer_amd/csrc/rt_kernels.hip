@@ -720,7 +720,7 @@ __device__ __forceinline__ void wave_add_total(uint64_t *stats, int slot, uint32
 template <bool TILED, bool STATS, bool TABLDS, typename EyeSource>
 __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCamera &C,
                                                 const DevWork &Wk, const float4 *lds_poly,
-                                                float4 *lds_sph, uint32_t *lds_vis,
+                                                float4 *lds_sph, uint32_t *lds_vis, float *lds_park,
                                                 const Tables<TABLDS> &tab, bool hit,
                                                 const EyeSource &eye_src, float px, float py, float pz,
                                                 uint32_t obj, uint32_t level,
@@ -901,8 +901,14 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
      */
     Ray cr; /* the child ray being traced */
     bool hit_r = false, hit_t = false;
-    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0; /* reflection child's queue entry */
-    float4 t0 = r0, t1 = r0, t2 = r0;                              /* transmission child's        */
+    float *const park = lds_park + 6u * RT_BLOCK + threadIdx.x; /* the reflection child's queue entry waits
+                                                                   here; the transmission child's is what
+                                                                   the loop leaves behind in cr, cd, cobj */
+    float cd = 0.0f;
+    uint32_t cobj = RT_NONE;
+    /* the node's own colour and coefficients sit out the two searches in LDS */
+    park[10 * RT_BLOCK] = outr; park[11 * RT_BLOCK] = outg; park[12 * RT_BLOCK] = outb;
+    park[13 * RT_BLOCK] = kr; park[14 * RT_BLOCK] = kt;
 #pragma unroll 1
     for (uint32_t child = 0; child < 2u; ++child) {
         const bool want = child ? want_t : want_r;
@@ -943,32 +949,36 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
         if (!want) {
             cr.ox = cr.oy = cr.oz = cr.dx = cr.dy = cr.dz = cr.mag = 0.0f;
         }
-        float cd;
-        uint32_t cobj;
         intersect_all<TILED, true, false, STATS>(S, lds_poly, lds_sph, want, cr, RT_NONE, RT_NONE, cd, cobj, tl);
         const bool chit = want && (cobj != RT_NONE);
-        /* the child's hit point, as its get_ray_color would form it (ray.c:121-122, 236-237) */
-        const float4 e0 = make_float4(cr.ox + cr.dx * cd, cr.oy + cr.dy * cd, cr.oz + cr.dz * cd,
-                                      __uint_as_float(cobj));
         if (child == 0u) {
             hit_r = chit;
-            r0 = e0;
-            r1 = make_float4(cr.ox, cr.oy, cr.oz, 0.f);
-            r2 = make_float4(cr.dx, cr.dy, cr.dz, 0.f);
+            /* the child's hit point, as its get_ray_color would form it (ray.c:121-122, 236-237) */
+            park[0 * RT_BLOCK] = cr.ox + cr.dx * cd;
+            park[1 * RT_BLOCK] = cr.oy + cr.dy * cd;
+            park[2 * RT_BLOCK] = cr.oz + cr.dz * cd;
+            park[3 * RT_BLOCK] = __uint_as_float(cobj);
+            park[4 * RT_BLOCK] = cr.ox; park[5 * RT_BLOCK] = cr.oy; park[6 * RT_BLOCK] = cr.oz;
+            park[7 * RT_BLOCK] = cr.dx; park[8 * RT_BLOCK] = cr.dy; park[9 * RT_BLOCK] = cr.dz;
         } else {
             hit_t = chit;
-            t0 = e0;
-            t1 = make_float4(cr.ox, cr.oy, cr.oz, 0.f);
-            t2 = make_float4(cr.dx, cr.dy, cr.dz, 0.f);
         }
     }
     if (!hit)
         return false;
+    float kr2, kt2;
+    {
+        uint32_t t = threadIdx.x;
+        asm volatile("" : "+v"(t)); /* opaque index: the compiler must not keep the parked values in registers */
+        const float *back = lds_park + 6u * RT_BLOCK + t;
+        outr = back[10 * RT_BLOCK]; outg = back[11 * RT_BLOCK]; outb = back[12 * RT_BLOCK];
+        kr2 = back[13 * RT_BLOCK]; kt2 = back[14 * RT_BLOCK];
+    }
     if (!(hit_r || hit_t)) {
         /* every child (if any) left the scene: the node is finished.  Same expression order as
          * fold_values: local + kr*child, then + kt*child, then the clamp (raytrace.c:440-442,547-549,562) */
-        if (want_r) { outr += kr * S.bg[0]; outg += kr * S.bg[1]; outb += kr * S.bg[2]; }
-        if (want_t) { outr += kt * S.bg[0]; outg += kt * S.bg[1]; outb += kt * S.bg[2]; }
+        if (want_r) { outr += kr2 * S.bg[0]; outg += kr2 * S.bg[1]; outb += kr2 * S.bg[2]; }
+        if (want_t) { outr += kt2 * S.bg[0]; outg += kt2 * S.bg[1]; outb += kt2 * S.bg[2]; }
         leaf[0] = clamp1(outr);
         leaf[1] = clamp1(outg);
         leaf[2] = clamp1(outb);
@@ -988,8 +998,8 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     }
     const uint32_t node = node_base + local;
     node_idx = node;
-    Wk.nodeA[node] = make_float4(outr, outg, outb, kr);
-    Wk.nodeK[node] = make_float2(kt, __uint_as_float(link | (want_r ? 2u : 0u) | (want_t ? 4u : 0u)));
+    Wk.nodeA[node] = make_float4(outr, outg, outb, kr2);
+    Wk.nodeK[node] = make_float2(kt2, __uint_as_float(link | (want_r ? 2u : 0u) | (want_t ? 4u : 0u)));
     const float4 bg4 = make_float4(S.bg[0], S.bg[1], S.bg[2], 0.0f);
     if (want_r && !hit_r)
         Wk.childR[node] = bg4;
@@ -1004,16 +1014,17 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     float4 *const outC = odd_next ? Wk.qC[1] : Wk.qC[0];
     const uint32_t qbase = shard * Wk.capS;
     if (slot_r != RT_NONE) {
-        r1.w = __uint_as_float((node << 1) | 0u);
-        outA[qbase + slot_r] = r0;
-        outB[qbase + slot_r] = r1;
-        outC[qbase + slot_r] = r2;
+        outA[qbase + slot_r] = make_float4(park[0 * RT_BLOCK], park[1 * RT_BLOCK], park[2 * RT_BLOCK],
+                                           park[3 * RT_BLOCK]);
+        outB[qbase + slot_r] = make_float4(park[4 * RT_BLOCK], park[5 * RT_BLOCK], park[6 * RT_BLOCK],
+                                           __uint_as_float((node << 1) | 0u));
+        outC[qbase + slot_r] = make_float4(park[7 * RT_BLOCK], park[8 * RT_BLOCK], park[9 * RT_BLOCK], 0.f);
     }
     if (slot_t != RT_NONE) {
-        t1.w = __uint_as_float((node << 1) | 1u);
-        outA[qbase + slot_t] = t0;
-        outB[qbase + slot_t] = t1;
-        outC[qbase + slot_t] = t2;
+        outA[qbase + slot_t] = make_float4(cr.ox + cr.dx * cd, cr.oy + cr.dy * cd, cr.oz + cr.dz * cd,
+                                           __uint_as_float(cobj));
+        outB[qbase + slot_t] = make_float4(cr.ox, cr.oy, cr.oz, __uint_as_float((node << 1) | 1u));
+        outC[qbase + slot_t] = make_float4(cr.dx, cr.dy, cr.dz, 0.f);
     }
     pc.mark(6);
     return true;
@@ -1060,7 +1071,6 @@ struct PrimaryEye {
 /* k_bounce parks the ray in LDS (one column per thread, SoA rows: conflict-free) rather than
  * re-reading the queue: on gfx950 a global load issued after the previous iteration's stores waits
  * for their write acknowledgements as well (one in-order counter), an LDS read does not. */
-#define RT_EYE_STASH_FLOATS (6u * RT_BLOCK)
 struct StashedEye {
     const float *lds_eye;
     __device__ __forceinline__ static void park(float *lds_eye, const Ray &r)
@@ -1118,12 +1128,13 @@ __device__ __forceinline__ void flush_tally(uint64_t *st, Tally<STATS> &tl, bool
 /* k_primary: get_pixel_color + get_ray_color + depth-0 get_shade_color_phong, fused           */
 /* ------------------------------------------------------------------------------------------ */
 template <bool TILED, bool STATS, bool TABLDS>
-__global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_primary(DevScene S, DevCamera C, DevWork Wk,
+__global__ __launch_bounds__(RT_BLOCK, 5) void k_primary(DevScene S, DevCamera C, DevWork Wk,
                                                       DevRows R)
 {
     extern __shared__ __attribute__((aligned(16))) float4 lds[];
-    float4 *lds_poly = lds;
-    float4 *lds_sph = lds + S.nPolySlots;
+    float *lds_park = (float *)lds; /* RT_PARK_FLOATS, ahead of the scene data */
+    float4 *lds_poly = lds + RT_PARK_FLOATS / 4u;
+    float4 *lds_sph = lds_poly + S.nPolySlots;
     uint32_t *lds_vis = (uint32_t *)(lds_sph + sphere_slots(S.nSph));
     const Tables<TABLDS> tab = stage_tables<TABLDS>(S, lds_vis);
     block_copy(lds_poly, S.poly, S.nPolySlots);
@@ -1172,7 +1183,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_primary(DevScene S, DevCam
             bool sr, st_;
             const float px = r.ox + r.dx * d, py = r.oy + r.dy * d, pz = r.oz + r.dz * d;
             const PrimaryEye eye_src{C, fu0, fv0, i, j};
-            const bool deferred = shade_and_spawn<TILED, STATS, TABLDS>(S, C, Wk, lds_poly, lds_sph, lds_vis, tab, hit,
+            const bool deferred = shade_and_spawn<TILED, STATS, TABLDS>(S, C, Wk, lds_poly, lds_sph, lds_vis, lds_park, tab, hit,
                                                                 eye_src, px, py, pz, obj, 0u, RT_LINK_NONE << 3, shard,
                                                                 node_base, Wk.capS, leaf, node, sr, st_, tl, pc);
             sc.add(hit, sr, st_);
@@ -1204,8 +1215,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_bounce(DevScene S, DevCame
                                                      uint32_t level)
 {
     extern __shared__ __attribute__((aligned(16))) float4 lds[];
-    float *lds_eye = (float *)lds; /* RT_EYE_STASH_FLOATS, ahead of the scene data */
-    float4 *lds_poly = lds + RT_EYE_STASH_FLOATS / 4u;
+    float *lds_park = (float *)lds; /* RT_PARK_FLOATS, ahead of the scene data */
+    float *lds_eye = lds_park;
+    float4 *lds_poly = lds + RT_PARK_FLOATS / 4u;
     float4 *lds_sph = lds_poly + S.nPolySlots;
     uint32_t *lds_vis = (uint32_t *)(lds_sph + sphere_slots(S.nSph));
 
@@ -1290,7 +1302,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_bounce(DevScene S, DevCame
         bool sr, st_;
         StashedEye::park(lds_eye, r);
         const StashedEye eye_src{lds_eye};
-        const bool deferred = shade_and_spawn<TILED, STATS, TABLDS>(S, C, Wk, lds_poly, lds_sph, lds_vis, tab, hit, eye_src,
+        const bool deferred = shade_and_spawn<TILED, STATS, TABLDS>(S, C, Wk, lds_poly, lds_sph, lds_vis, lds_park, tab, hit, eye_src,
                                                             px, py, pz, obj, level,
                                                             ((parent >> 1) << 3) | (parent & 1u), shard, node_base,
                                                             node_room, leaf, node, sr, st_, tl, pc);
@@ -1434,7 +1446,8 @@ size_t rt_scene_lds_bytes(const DevScene &S)
     const uint32_t sph = sphere_slots(S.nSph);
     /* + one visibility word per thread for every full group of 32 lights before the last group,
      * + the light / object tables when they are staged */
-    return (size_t)(S.nPolySlots + sph) * sizeof(float4) + (size_t)vis_words(S.nLights) * sizeof(uint32_t) +
+    return RT_PARK_FLOATS * sizeof(float) + (size_t)(S.nPolySlots + sph) * sizeof(float4) +
+           (size_t)vis_words(S.nLights) * sizeof(uint32_t) +
            (S.tabInLds ? (size_t)S.tabSlots * sizeof(float4) : 0);
 }
 
@@ -1491,7 +1504,7 @@ static uint32_t queue_grid(const DevWork &Wk, const void *kernel, size_t lds)
 void rt_launch_bounce(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t level,
                       bool stats, hipStream_t stream)
 {
-    const size_t lds = rt_scene_lds_bytes(S) + RT_EYE_STASH_FLOATS * sizeof(float);
+    const size_t lds = rt_scene_lds_bytes(S);
     const bool tiled = S.nSph > RT_TILE_SPHERES;
     void (*kernel)(DevScene, DevCamera, DevWork, uint32_t) =
         tiled ? (stats ? k_bounce<true, true, false> : k_bounce<true, false, false>)
