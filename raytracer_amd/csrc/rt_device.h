@@ -16,10 +16,9 @@
 #define RT_MAX_POLY_LDS 1024        /* float4 slots for planes + info + vertices in LDS */
 #define RT_BLOCK        256
 /* per-thread parking area at the start of every trace kernel's LDS (row-major [word][thread],
- * conflict-free): words 0-5 the eye ray of k_bounce, 6-15 the reflection child's queue entry while
- * the transmission child is traced, 16-20 the node's local colour, kr and kt while its children
- * are traced.  Values parked here do not occupy VGPRs across the searches. */
-#define RT_PARK_WORDS   21u
+ * conflict-free; rows listed in shade_and_spawn).  Values parked here do not occupy VGPRs across
+ * the intersection searches. */
+#define RT_PARK_WORDS   22u
 #define RT_PARK_FLOATS  (RT_PARK_WORDS * RT_BLOCK)
 
 /* Camera constants, pre-folded on the host with the reference's float rounding

@@ -899,67 +899,80 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
      * did hit something.  The queues carry hits (point, object, the ray that found it), so the
      * consumer starts at the shading.
      */
-    Ray cr; /* the child ray being traced */
+    /* Both child rays are built first; the transmission ray, the node's own colour and its
+     * coefficients then sit in LDS while the searches run (rows of RT_PARK_WORDS):
+     *   0-6   transmission ray (o, d, magnitude) - over the eye ray k_bounce parked there, which
+     *         is not needed once both rays exist
+     *   7-16  the reflection child's queue entry (point, object, ray origin, ray direction)
+     *   17-21 local colour, kr, kt                                                          */
+    float *const park = lds_park + threadIdx.x;
+    Ray cr; /* the child ray being traced: the reflection ray first */
+    cr.ox = cr.oy = cr.oz = cr.dx = cr.dy = cr.dz = cr.mag = 0.0f;
+    {
+        Ray tr;
+        tr.ox = tr.oy = tr.oz = tr.dx = tr.dy = tr.dz = tr.mag = 0.0f;
+        if (want_t) { /* transmission ray raytrace.c:455-537 */
+            float nit = 1.0f / mD.x;
+            float edx, edy, edz;
+            eye_src.direction(edx, edy, edz);
+            const float Tx = edx * nit, Ty = edy * nit, Tz = edz * nit;
+            const float cs = dot3(Vx, Vy, Vz, Nx, Ny, Nz);
+            float Fx = Nx, Fy = Ny, Fz = Nz;
+            if (cs < 0.0f) { /* inside the object moving out */
+                nit = 1.0f / nit;
+                Fx = Nx * -1.0f; Fy = Ny * -1.0f; Fz = Nz * -1.0f;
+            }
+            const float det = 1.0f + (nit * nit) * (cs * cs - 1.0f);
+            tr.ox = px; tr.oy = py; tr.oz = pz;
+            if (det < 0.0f) { /* total internal reflection :470-489 */
+                const float t2x = 2.0f * dot3(Vx, Vy, Vz, Fx, Fy, Fz);
+                tr.dx = Fx * t2x - Vx; tr.dy = Fy * t2x - Vy; tr.dz = Fz * t2x - Vz;
+                tr.mag = 999999.0f;
+            } else { /* :517-525: 1/n (not nit) times cos, minus a double sqrt */
+                const float k = (float)((double)((1.0f / mD.x) * cs) - sqrt((double)det));
+                tr.dx = Tx + Fx * k; tr.dy = Ty + Fy * k; tr.dz = Tz + Fz * k;
+                tr.mag = 99999.9f;
+            }
+            tinypush(tr);
+        }
+        if (want_r) { /* reflection ray raytrace.c:408-425 */
+            const float t2x = 2.0f * dot3(Vx, Vy, Vz, Nx, Ny, Nz);
+            cr.ox = px; cr.oy = py; cr.oz = pz;
+            cr.dx = Nx * t2x - Vx; cr.dy = Ny * t2x - Vy; cr.dz = Nz * t2x - Vz;
+            cr.mag = 9999999.9f;
+            tinypush(cr);
+        }
+        park[0 * RT_BLOCK] = tr.ox; park[1 * RT_BLOCK] = tr.oy; park[2 * RT_BLOCK] = tr.oz;
+        park[3 * RT_BLOCK] = tr.dx; park[4 * RT_BLOCK] = tr.dy; park[5 * RT_BLOCK] = tr.dz;
+        park[6 * RT_BLOCK] = tr.mag;
+        park[17 * RT_BLOCK] = outr; park[18 * RT_BLOCK] = outg; park[19 * RT_BLOCK] = outb;
+        park[20 * RT_BLOCK] = kr; park[21 * RT_BLOCK] = kt;
+    }
     bool hit_r = false, hit_t = false;
-    float *const park = lds_park + 6u * RT_BLOCK + threadIdx.x; /* the reflection child's queue entry waits
-                                                                   here; the transmission child's is what
-                                                                   the loop leaves behind in cr, cd, cobj */
     float cd = 0.0f;
     uint32_t cobj = RT_NONE;
-    /* the node's own colour and coefficients sit out the two searches in LDS */
-    park[10 * RT_BLOCK] = outr; park[11 * RT_BLOCK] = outg; park[12 * RT_BLOCK] = outb;
-    park[13 * RT_BLOCK] = kr; park[14 * RT_BLOCK] = kt;
 #pragma unroll 1
     for (uint32_t child = 0; child < 2u; ++child) {
         const bool want = child ? want_t : want_r;
-        if (child == 0u) {
-            if (want) { /* reflection ray raytrace.c:408-425 */
-                const float t2x = 2.0f * dot3(Vx, Vy, Vz, Nx, Ny, Nz);
-                cr.ox = px; cr.oy = py; cr.oz = pz;
-                cr.dx = Nx * t2x - Vx; cr.dy = Ny * t2x - Vy; cr.dz = Nz * t2x - Vz;
-                cr.mag = 9999999.9f;
-                tinypush(cr);
-            }
-        } else {
-            if (want) { /* transmission ray raytrace.c:455-537 */
-                float nit = 1.0f / mD.x;
-                float edx, edy, edz;
-                eye_src.direction(edx, edy, edz);
-                const float Tx = edx * nit, Ty = edy * nit, Tz = edz * nit;
-                const float cs = dot3(Vx, Vy, Vz, Nx, Ny, Nz);
-                float Fx = Nx, Fy = Ny, Fz = Nz;
-                if (cs < 0.0f) { /* inside the object moving out */
-                    nit = 1.0f / nit;
-                    Fx = Nx * -1.0f; Fy = Ny * -1.0f; Fz = Nz * -1.0f;
-                }
-                const float det = 1.0f + (nit * nit) * (cs * cs - 1.0f);
-                cr.ox = px; cr.oy = py; cr.oz = pz;
-                if (det < 0.0f) { /* total internal reflection :470-489 */
-                    const float t2x = 2.0f * dot3(Vx, Vy, Vz, Fx, Fy, Fz);
-                    cr.dx = Fx * t2x - Vx; cr.dy = Fy * t2x - Vy; cr.dz = Fz * t2x - Vz;
-                    cr.mag = 999999.0f;
-                } else { /* :517-525: 1/n (not nit) times cos, minus a double sqrt */
-                    const float k = (float)((double)((1.0f / mD.x) * cs) - sqrt((double)det));
-                    cr.dx = Tx + Fx * k; cr.dy = Ty + Fy * k; cr.dz = Tz + Fz * k;
-                    cr.mag = 99999.9f;
-                }
-                tinypush(cr);
-            }
-        }
-        if (!want) {
-            cr.ox = cr.oy = cr.oz = cr.dx = cr.dy = cr.dz = cr.mag = 0.0f;
+        if (child != 0u) { /* the transmission ray, back from LDS (opaque index: no register forwarding) */
+            uint32_t t = threadIdx.x;
+            asm volatile("" : "+v"(t));
+            const float *back = lds_park + t;
+            cr.ox = back[0 * RT_BLOCK]; cr.oy = back[1 * RT_BLOCK]; cr.oz = back[2 * RT_BLOCK];
+            cr.dx = back[3 * RT_BLOCK]; cr.dy = back[4 * RT_BLOCK]; cr.dz = back[5 * RT_BLOCK];
+            cr.mag = back[6 * RT_BLOCK];
         }
         intersect_all<TILED, true, false, STATS>(S, lds_poly, lds_sph, want, cr, RT_NONE, RT_NONE, cd, cobj, tl);
         const bool chit = want && (cobj != RT_NONE);
         if (child == 0u) {
             hit_r = chit;
             /* the child's hit point, as its get_ray_color would form it (ray.c:121-122, 236-237) */
-            park[0 * RT_BLOCK] = cr.ox + cr.dx * cd;
-            park[1 * RT_BLOCK] = cr.oy + cr.dy * cd;
-            park[2 * RT_BLOCK] = cr.oz + cr.dz * cd;
-            park[3 * RT_BLOCK] = __uint_as_float(cobj);
-            park[4 * RT_BLOCK] = cr.ox; park[5 * RT_BLOCK] = cr.oy; park[6 * RT_BLOCK] = cr.oz;
-            park[7 * RT_BLOCK] = cr.dx; park[8 * RT_BLOCK] = cr.dy; park[9 * RT_BLOCK] = cr.dz;
+            park[7 * RT_BLOCK] = cr.ox + cr.dx * cd;
+            park[8 * RT_BLOCK] = cr.oy + cr.dy * cd;
+            park[9 * RT_BLOCK] = cr.oz + cr.dz * cd;
+            park[10 * RT_BLOCK] = __uint_as_float(cobj);
+            park[11 * RT_BLOCK] = cr.ox; park[12 * RT_BLOCK] = cr.oy; park[13 * RT_BLOCK] = cr.oz;
+            park[14 * RT_BLOCK] = cr.dx; park[15 * RT_BLOCK] = cr.dy; park[16 * RT_BLOCK] = cr.dz;
         } else {
             hit_t = chit;
         }
@@ -970,9 +983,9 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     {
         uint32_t t = threadIdx.x;
         asm volatile("" : "+v"(t)); /* opaque index: the compiler must not keep the parked values in registers */
-        const float *back = lds_park + 6u * RT_BLOCK + t;
-        outr = back[10 * RT_BLOCK]; outg = back[11 * RT_BLOCK]; outb = back[12 * RT_BLOCK];
-        kr2 = back[13 * RT_BLOCK]; kt2 = back[14 * RT_BLOCK];
+        const float *back = lds_park + t;
+        outr = back[17 * RT_BLOCK]; outg = back[18 * RT_BLOCK]; outb = back[19 * RT_BLOCK];
+        kr2 = back[20 * RT_BLOCK]; kt2 = back[21 * RT_BLOCK];
     }
     if (!(hit_r || hit_t)) {
         /* every child (if any) left the scene: the node is finished.  Same expression order as
@@ -1014,11 +1027,11 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     float4 *const outC = odd_next ? Wk.qC[1] : Wk.qC[0];
     const uint32_t qbase = shard * Wk.capS;
     if (slot_r != RT_NONE) {
-        outA[qbase + slot_r] = make_float4(park[0 * RT_BLOCK], park[1 * RT_BLOCK], park[2 * RT_BLOCK],
-                                           park[3 * RT_BLOCK]);
-        outB[qbase + slot_r] = make_float4(park[4 * RT_BLOCK], park[5 * RT_BLOCK], park[6 * RT_BLOCK],
+        outA[qbase + slot_r] = make_float4(park[7 * RT_BLOCK], park[8 * RT_BLOCK], park[9 * RT_BLOCK],
+                                           park[10 * RT_BLOCK]);
+        outB[qbase + slot_r] = make_float4(park[11 * RT_BLOCK], park[12 * RT_BLOCK], park[13 * RT_BLOCK],
                                            __uint_as_float((node << 1) | 0u));
-        outC[qbase + slot_r] = make_float4(park[7 * RT_BLOCK], park[8 * RT_BLOCK], park[9 * RT_BLOCK], 0.f);
+        outC[qbase + slot_r] = make_float4(park[14 * RT_BLOCK], park[15 * RT_BLOCK], park[16 * RT_BLOCK], 0.f);
     }
     if (slot_t != RT_NONE) {
         outA[qbase + slot_t] = make_float4(cr.ox + cr.dx * cd, cr.oy + cr.dy * cd, cr.oz + cr.dz * cd,
@@ -1128,7 +1141,7 @@ __device__ __forceinline__ void flush_tally(uint64_t *st, Tally<STATS> &tl, bool
 /* k_primary: get_pixel_color + get_ray_color + depth-0 get_shade_color_phong, fused           */
 /* ------------------------------------------------------------------------------------------ */
 template <bool TILED, bool STATS, bool TABLDS>
-__global__ __launch_bounds__(RT_BLOCK, 5) void k_primary(DevScene S, DevCamera C, DevWork Wk,
+__global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_primary(DevScene S, DevCamera C, DevWork Wk,
                                                       DevRows R)
 {
     extern __shared__ __attribute__((aligned(16))) float4 lds[];
