@@ -92,6 +92,12 @@ struct rt_hip_ctx {
                                         on one stream and hide each other's host latency */
     size_t cwords = RT_COUNTER_WORDS; /* counter words in use per batch (depends on depth) */
     rt_hip_stats stats{};
+    /* largest per-shard entry counts the last checked batch produced per level (hits queued for the
+     * level, nodes made at it): they size the next batch's bounce / fold grids */
+    uint32_t seen_hits[RT_MAX_LEVELS] = {0};
+    uint32_t seen_nodes[RT_MAX_LEVELS] = {0};
+    bool seen_valid = false;
+    uint64_t seen_key[3] = {0, 0, 0}; /* frame the counts belong to: they are dropped when it changes */
 };
 
 namespace {
@@ -192,9 +198,9 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
         HIP_TRY(hipEventRecord(c->ev.back(), st));
     const uint32_t depth = c->C.depth;
     for (uint32_t d = 1; d <= depth; ++d)
-        rt_launch_bounce(c->S, c->C, Wk, d, stats, st);
+        rt_launch_bounce(c->S, c->C, Wk, d, stats, c->seen_valid ? (c->seen_hits[d] ? c->seen_hits[d] : 1u) : 0u, st);
     for (uint32_t d = depth; d-- > 1;) /* nodes exist on levels 0..depth-1; level 0 folds in resolve */
-        rt_launch_fold(Wk, d, st);
+        rt_launch_fold(Wk, d, c->seen_valid ? (c->seen_nodes[d] ? c->seen_nodes[d] : 1u) : 0u, st);
     rt_launch_resolve(c->C, Wk, R, c->d_argb, c->d_rad, st);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -215,6 +221,25 @@ bool batch_overflowed(const uint32_t *cnt)
         if (cnt[CNT_OVERFLOW + l])
             return true;
     return false;
+}
+
+/* remember how full the level queues / node ranges of a batch got (grid sizing of the next one) */
+void note_levels(rt_hip_ctx *c, const uint32_t *cnt, uint32_t levels, bool first)
+{
+    if (first) {
+        memset(c->seen_hits, 0, sizeof c->seen_hits);
+        memset(c->seen_nodes, 0, sizeof c->seen_nodes);
+    }
+    for (uint32_t l = 0; l < levels && l + 1 < RT_MAX_LEVELS; ++l)
+        for (uint32_t sh = 0; sh < RT_SHARDS; ++sh) {
+            const uint64_t v = *(const uint64_t *)(cnt + CNT_LEVELS + (l * RT_SHARDS + sh) * RT_LINE_WORDS);
+            const uint32_t nodes = (uint32_t)v, hits = (uint32_t)(v >> 32);
+            if (nodes > c->seen_nodes[l])
+                c->seen_nodes[l] = nodes;
+            if (hits > c->seen_hits[l + 1])
+                c->seen_hits[l + 1] = hits;
+        }
+    c->seen_valid = true;
 }
 
 void accumulate(rt_hip_stats &s, const uint32_t *cnt, uint32_t levels)
@@ -313,6 +338,7 @@ int drain(rt_hip_ctx *c)
                 c->todo.push_back({b.t0, mid, 0});
             } else {
                 accumulate(c->stats, cnt, c->C.depth + 1);
+                note_levels(c, cnt, c->C.depth + 1, c->stats.batches == 0);
                 c->stats.batches++;
             }
         }
@@ -617,6 +643,7 @@ int rt_hip_scene_upload(rt_hip_ctx *c, const rt_scene *sc)
         return RT_E_INVALID;
     }
     c->have_scene = true;
+    c->seen_valid = false;
     return 0;
 }
 
@@ -635,6 +662,15 @@ static int submit(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb, float *
     }
     c->cam = *cam;
     fold_camera(c->C, *cam);
+    {
+        const uint64_t key[3] = {((uint64_t)cam->frameBufferWidth << 32) | cam->frameBufferHeight,
+                                 ((uint64_t)cam->sqrtSpp << 32) | cam->depth,
+                                 ((uint64_t)job.ntiles << 32) | (job.interleaved ? job.nphases : 0u)};
+        if (memcmp(key, c->seen_key, sizeof key) != 0) {
+            memcpy(c->seen_key, key, sizeof key);
+            c->seen_valid = false;
+        }
+    }
     c->cwords = RT_COUNTER_WORDS_FOR(cam->depth + 2);
     c->d_argb = d_argb;
     c->d_rad = d_rad;

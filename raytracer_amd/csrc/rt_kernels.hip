@@ -1484,7 +1484,7 @@ void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk,
  * rounded down to whole shards: a few blocks more and they would run as a second round after the
  * first has drained, doubling a latency-bound kernel (measured with 2048 blocks at 7 per CU).
  */
-static uint32_t queue_grid(const DevWork &Wk, const void *kernel, size_t lds)
+static uint32_t queue_grid(const DevWork &Wk, const void *kernel, size_t lds, uint32_t expect)
 {
     struct Entry { const void *kernel; size_t lds; int device; uint32_t blocks; };
     static Entry cache[16];
@@ -1506,7 +1506,12 @@ static uint32_t queue_grid(const DevWork &Wk, const void *kernel, size_t lds)
             cache[ncache++] = {kernel, lds, device, resident};
     }
     uint32_t slices = resident / RT_SHARDS;
-    const uint32_t most = (Wk.capS + RT_BLOCK - 1) / RT_BLOCK;
+    uint32_t most = (Wk.capS + RT_BLOCK - 1) / RT_BLOCK;
+    if (expect) { /* the deep levels hold a few thousand entries: do not launch 1500 blocks for them */
+        const uint32_t want = (uint32_t)(((uint64_t)expect * 2u + RT_BLOCK - 1) / RT_BLOCK);
+        if (want < most)
+            most = want;
+    }
     if (slices > most)
         slices = most;
     if (slices < 1)
@@ -1515,7 +1520,7 @@ static uint32_t queue_grid(const DevWork &Wk, const void *kernel, size_t lds)
 }
 
 void rt_launch_bounce(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t level,
-                      bool stats, hipStream_t stream)
+                      bool stats, uint32_t expect, hipStream_t stream)
 {
     const size_t lds = rt_scene_lds_bytes(S);
     const bool tiled = S.nSph > RT_TILE_SPHERES;
@@ -1523,13 +1528,13 @@ void rt_launch_bounce(const DevScene &S, const DevCamera &C, const DevWork &Wk, 
         tiled ? (stats ? k_bounce<true, true, false> : k_bounce<true, false, false>)
         : S.tabInLds ? (stats ? k_bounce<false, true, true> : k_bounce<false, false, true>)
                      : (stats ? k_bounce<false, true, false> : k_bounce<false, false, false>);
-    const uint32_t grid = queue_grid(Wk, (const void *)kernel, lds);
+    const uint32_t grid = queue_grid(Wk, (const void *)kernel, lds, expect);
     kernel<<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, level);
 }
 
-void rt_launch_fold(const DevWork &Wk, uint32_t level, hipStream_t stream)
+void rt_launch_fold(const DevWork &Wk, uint32_t level, uint32_t expect, hipStream_t stream)
 {
-    k_fold<<<queue_grid(Wk, (const void *)k_fold, 0), RT_BLOCK, 0, stream>>>(Wk, level);
+    k_fold<<<queue_grid(Wk, (const void *)k_fold, 0, expect), RT_BLOCK, 0, stream>>>(Wk, level);
 }
 
 void rt_launch_resolve(const DevCamera &C, const DevWork &Wk, const DevRows &R, uint32_t *d_argb,
