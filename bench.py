@@ -59,6 +59,20 @@ def algorithmic_flops_k0(st, samples, n_lights, nv=4):
     return sph + poly + gen + nodes + lights + spawn
 
 
+def measured_traffic(W, H, sqrt_spp, depth):
+    """HBM bytes per k_primary launch from the committed PMC passes (profiles/r01_traffic.json:
+    FETCH_SIZE / WRITE_SIZE collected in separate rocprofv3 runs, corrected as the MI355X guide
+    prescribes).  Only for the workload they were collected on; otherwise None."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+    except OSError:
+        return None
+    w = t["workload"]
+    if (w["W"], w["H"], w["sqrt_spp"], w["depth"]) != (W, H, sqrt_spp, depth):
+        return None
+    return t["k_primary"]["bytes_per_launch"]
+
+
 def cpu_baseline(W, H, sqrt_spp, depth, budget_rows):
     """Reference (oracle/_ref, when it travelled) or the oracle port on ONE host core, on a row
     slab of the same frame.  Returns the JSON object."""
@@ -228,7 +242,9 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else f"cyclic 8-row blocks over {world} GPUs"},
             "roofline": {"bound": "fp32_valu", "kernel": "k_primary", "achieved": achieved,
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
-                         "traffic": None, "algorithmic_flop_per_launch": flops_k0 / max(launches_per_step, 1),
+                         "traffic": measured_traffic(W, H, sqrt_spp, depth) if world == 1 else None,
+                         "traffic_unit": "bytes per launch (PMC, profiles/r01_traffic.json)",
+                         "algorithmic_flop_per_launch": flops_k0 / max(launches_per_step, 1),
                          "avg_launch_ms": k0_avg_ms},
         }
         if world == 1 and not args.no_cpu_baseline:
