@@ -476,16 +476,8 @@ int rt_hip_ctx_create(rt_hip_ctx **out, int device, uint64_t max_queue_rays)
         return -(int)e;
     }
     char *p = (char *)c->work_blob;
-    c->W.qA[0] = (float4 *)(p + 0 * arr);
-    c->W.qB[0] = (float4 *)(p + 1 * arr);
-    c->W.qA[1] = (float4 *)(p + 2 * arr);
-    c->W.qB[1] = (float4 *)(p + 3 * arr);
-    c->W.qC[0] = (float4 *)(p + 4 * arr);
-    c->W.qC[1] = (float4 *)(p + 5 * arr);
-    c->W.nodeA = (float4 *)(p + 6 * arr);
-    c->W.childR = (float4 *)(p + 7 * arr);
-    c->W.childT = (float4 *)(p + 8 * arr);
-    c->W.nodeK = (float2 *)(p + 9 * arr); /* half an array */
+    c->W.base = p; /* slots 0..9, the last one (float2) half as long: rt_device.h */
+    c->W.stride = arr;
     c->W.cap = (uint32_t)cap;
     c->W.capS = (uint32_t)(cap / RT_SHARDS);
     *out = c;

@@ -79,15 +79,20 @@ struct DevRows {
 
 /* Per-batch work state in HBM. */
 struct DevWork {
-    float4 *qA[2];        /* hit queues, ping-pong by level parity: (hit point, bits object)      */
-    float4 *qB[2];        /*   (origin of the ray that found the hit, bits parent<<1|slot)        */
-    float4 *qC[2];        /*   (direction of that ray, -)                                         */
-    float4 *nodeA;        /* (local rgb, kr)                        written when the node is made */
-    float2 *nodeK;        /* (kt, bits link)                        written when the node is made */
-    float4 *childR;       /* (reflection child rgb, -)   written by the child, as a whole float4:  */
-    float4 *childT;       /* (transmission child rgb, -) consecutive rays have consecutive parents,
-                             so a wave's results are full-line stores (12-byte pieces of a shared
-                             float4 made every store a partial-sector read-modify-write)          */
+    /* Ten arrays of `cap` entries in one allocation, `stride` bytes apart, addressed from ONE base
+     * pointer: thirteen pointers as kernel arguments kept ~26 scalar registers live through the
+     * trace kernels, which spilled them into VGPR lanes (300 v_readlane / v_writelane in k_primary).
+     *   slot 3p+0  qA[p]  hit queue of level parity p: (hit point, bits object)
+     *   slot 3p+1  qB[p]  (origin of the ray that found the hit, bits parent<<1|slot)
+     *   slot 3p+2  qC[p]  (direction of that ray, -)
+     *   slot 6     nodeA  (local rgb, kr)                 written when the node is made
+     *   slot 7     childR (reflection child rgb, -)       written by the child, as a whole float4:
+     *   slot 8     childT (transmission child rgb, -)     consecutive rays have consecutive parents,
+     *                     so a wave's results are full-line stores (12-byte pieces of a shared float4
+     *                     made every store a partial-sector read-modify-write)
+     *   slot 9     nodeK  (kt, bits link), float2         written when the node is made           */
+    char *base;
+    uint64_t stride;
     float4 *pixAcc;       /* per pixel of the batch: (immediate sum rgb, bits #roots)  */
     uint32_t *roots;      /* [spp^2][pixels of the batch] k-th root node of a pixel: the roots of
                              a pixel are independent loads for k_resolve (a linked chain through
@@ -95,6 +100,15 @@ struct DevWork {
     uint32_t *counters;   /* counter block of this batch (layout below)                */
     uint32_t cap;         /* entries per queue / node pool                             */
     uint32_t capS;        /* entries per shard = cap / RT_SHARDS                       */
+
+    __host__ __device__ __forceinline__ float4 *slot(uint32_t k) const { return (float4 *)(base + (uint64_t)k * stride); }
+    __host__ __device__ __forceinline__ float4 *qA(uint32_t parity) const { return slot(3u * parity + 0u); }
+    __host__ __device__ __forceinline__ float4 *qB(uint32_t parity) const { return slot(3u * parity + 1u); }
+    __host__ __device__ __forceinline__ float4 *qC(uint32_t parity) const { return slot(3u * parity + 2u); }
+    __host__ __device__ __forceinline__ float4 *nodeA() const { return slot(6u); }
+    __host__ __device__ __forceinline__ float4 *childR() const { return slot(7u); }
+    __host__ __device__ __forceinline__ float4 *childT() const { return slot(8u); }
+    __host__ __device__ __forceinline__ float2 *nodeK() const { return (float2 *)slot(9u); }
 };
 
 /*

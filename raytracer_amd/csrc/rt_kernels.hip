@@ -1011,20 +1011,20 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     }
     const uint32_t node = node_base + local;
     node_idx = node;
-    Wk.nodeA[node] = make_float4(outr, outg, outb, kr2);
-    Wk.nodeK[node] = make_float2(kt2, __uint_as_float(link | (want_r ? 2u : 0u) | (want_t ? 4u : 0u)));
+    Wk.nodeA()[node] = make_float4(outr, outg, outb, kr2);
+    Wk.nodeK()[node] = make_float2(kt2, __uint_as_float(link | (want_r ? 2u : 0u) | (want_t ? 4u : 0u)));
     const float4 bg4 = make_float4(S.bg[0], S.bg[1], S.bg[2], 0.0f);
     if (want_r && !hit_r)
-        Wk.childR[node] = bg4;
+        Wk.childR()[node] = bg4;
     if (want_t && !hit_t)
-        Wk.childT[node] = bg4;
+        Wk.childT()[node] = bg4;
 
     /* queue of the next level: picked with selects - indexing the kernel-argument pointer array
      * with a run-time value makes the compiler re-load the pointer from memory at every use */
-    const bool odd_next = ((level + 1) & 1u) != 0;
-    float4 *const outA = odd_next ? Wk.qA[1] : Wk.qA[0];
-    float4 *const outB = odd_next ? Wk.qB[1] : Wk.qB[0];
-    float4 *const outC = odd_next ? Wk.qC[1] : Wk.qC[0];
+    const uint32_t odd_next = (level + 1) & 1u;
+    float4 *const outA = Wk.qA(odd_next);
+    float4 *const outB = Wk.qB(odd_next);
+    float4 *const outC = Wk.qC(odd_next);
     const uint32_t qbase = shard * Wk.capS;
     if (slot_r != RT_NONE) {
         outA[qbase + slot_r] = make_float4(park[7 * RT_BLOCK], park[8 * RT_BLOCK], park[9 * RT_BLOCK],
@@ -1043,18 +1043,36 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     return true;
 }
 
+/* Camera constants of the sample loop, kept in LDS (every lane reads the same words: broadcast)
+ * rather than in ~16 scalar registers for the whole kernel: the trace kernels run out of SGPRs and
+ * spill them into VGPR lanes. */
+enum { CAM_EYE = 0, CAM_U = 3, CAM_V = 6, CAM_SHIFTN = 9, CAM_SPPHALF = 12, CAM_SPPW = 13, CAM_WORDS = 16 };
+__device__ __forceinline__ void stage_camera(const DevCamera &C, float *cam)
+{
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 3; ++k) {
+            cam[CAM_EYE + k] = C.eye[k];
+            cam[CAM_U + k] = C.U[k];
+            cam[CAM_V + k] = C.V[k];
+            cam[CAM_SHIFTN + k] = C.shiftN[k];
+        }
+        cam[CAM_SPPHALF] = C.sppHalf;
+        cam[CAM_SPPW] = C.sppW;
+    }
+}
+
 /* get_pixel_color's ray of sub-sample (i,j) (raytrace.c:751-771): shift = N*vd + U*fu + V*fv;
  * target = eye + shift; ray_create(eye, target) */
-__device__ __forceinline__ void primary_ray(const DevCamera &C, float fu0, float fv0, uint32_t i,
+__device__ __forceinline__ void primary_ray(const float *cam, float fu0, float fv0, uint32_t i,
                                             uint32_t j, Ray &r)
 {
-    const float fv = fv0 + (C.sppHalf + (float)j * C.sppW);
-    const float fu = fu0 + (C.sppHalf + (float)i * C.sppW);
-    const float sx = (C.shiftN[0] + C.U[0] * fu) + C.V[0] * fv;
-    const float sy = (C.shiftN[1] + C.U[1] * fu) + C.V[1] * fv;
-    const float sz = (C.shiftN[2] + C.U[2] * fu) + C.V[2] * fv;
-    const float tx = C.eye[0] + sx, ty = C.eye[1] + sy, tz = C.eye[2] + sz;
-    r.ox = C.eye[0]; r.oy = C.eye[1]; r.oz = C.eye[2];
+    const float fv = fv0 + (cam[CAM_SPPHALF] + (float)j * cam[CAM_SPPW]);
+    const float fu = fu0 + (cam[CAM_SPPHALF] + (float)i * cam[CAM_SPPW]);
+    const float sx = (cam[CAM_SHIFTN + 0] + cam[CAM_U + 0] * fu) + cam[CAM_V + 0] * fv;
+    const float sy = (cam[CAM_SHIFTN + 1] + cam[CAM_U + 1] * fu) + cam[CAM_V + 1] * fv;
+    const float sz = (cam[CAM_SHIFTN + 2] + cam[CAM_U + 2] * fu) + cam[CAM_V + 2] * fv;
+    r.ox = cam[CAM_EYE + 0]; r.oy = cam[CAM_EYE + 1]; r.oz = cam[CAM_EYE + 2];
+    const float tx = r.ox + sx, ty = r.oy + sy, tz = r.oz + sz;
     r.dx = tx - r.ox; r.dy = ty - r.oy; r.dz = tz - r.oz;
     r.mag = mag3(r.dx, r.dy, r.dz);
     const float inv = recip_rn(r.mag);
@@ -1065,19 +1083,19 @@ __device__ __forceinline__ void primary_ray(const DevCamera &C, float fu0, float
  * asm makes the input opaque, so the compiler cannot fold the rebuild / re-read into the first
  * one and keep the values in registers across the any-hit searches after all. */
 struct PrimaryEye {
-    const DevCamera &C;
+    const float *cam;
     float fu0, fv0;
     uint32_t i, j;
     __device__ __forceinline__ void origin(float &x, float &y, float &z) const
     {
-        x = C.eye[0]; y = C.eye[1]; z = C.eye[2];
+        x = cam[CAM_EYE + 0]; y = cam[CAM_EYE + 1]; z = cam[CAM_EYE + 2];
     }
     __device__ __forceinline__ void direction(float &x, float &y, float &z) const
     {
         float f = fu0;
         asm volatile("" : "+v"(f));
         Ray r;
-        primary_ray(C, f, fv0, i, j, r);
+        primary_ray(cam, f, fv0, i, j, r);
         x = r.dx; y = r.dy; z = r.dz;
     }
 };
@@ -1150,6 +1168,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_primary(DevScene S, DevCam
     float4 *lds_sph = lds_poly + S.nPolySlots;
     uint32_t *lds_vis = (uint32_t *)(lds_sph + sphere_slots(S.nSph));
     const Tables<TABLDS> tab = stage_tables<TABLDS>(S, lds_vis);
+    __shared__ float cam[CAM_WORDS];
+    stage_camera(C, cam);
     block_copy(lds_poly, S.poly, S.nPolySlots);
     if (!TILED) {
         block_copy(lds_sph, S.sph, S.nSph);
@@ -1184,7 +1204,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_primary(DevScene S, DevCam
     for (uint32_t j = 0; j < C.sqrtSpp; ++j) {
         for (uint32_t i = 0; i < C.sqrtSpp; ++i) {
             Ray r;
-            primary_ray(C, fu0, fv0, i, j, r);
+            primary_ray(cam, fu0, fv0, i, j, r);
 
             float d;
             uint32_t obj;
@@ -1195,7 +1215,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_primary(DevScene S, DevCam
             uint32_t node;
             bool sr, st_;
             const float px = r.ox + r.dx * d, py = r.oy + r.dy * d, pz = r.oz + r.dz * d;
-            const PrimaryEye eye_src{C, fu0, fv0, i, j};
+            const PrimaryEye eye_src{cam, fu0, fv0, i, j};
             const bool deferred = shade_and_spawn<TILED, STATS, TABLDS>(S, C, Wk, lds_poly, lds_sph, lds_vis, lds_park, tab, hit,
                                                                 eye_src, px, py, pz, obj, 0u, RT_LINK_NONE << 3, shard,
                                                                 node_base, Wk.capS, leaf, node, sr, st_, tl, pc);
@@ -1272,9 +1292,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_bounce(DevScene S, DevCame
      * would also sit out the write latency of every store issued before it: measured, entry load
      * and store drain were 64 % of an iteration's ~13k cycles, the trace-and-shade work itself 36 %.
      */
-    const float4 *const inA = (level & 1u) ? Wk.qA[1] : Wk.qA[0]; /* selects, not indexing: see shade_and_spawn */
-    const float4 *const inB = (level & 1u) ? Wk.qB[1] : Wk.qB[0];
-    const float4 *const inC = (level & 1u) ? Wk.qC[1] : Wk.qC[0];
+    const float4 *const inA = Wk.qA(level & 1u);
+    const float4 *const inB = Wk.qB(level & 1u);
+    const float4 *const inC = Wk.qC(level & 1u);
     /* (loads are unconditional, on an index clamped into the shard's entries: a load under a branch
      * makes the compiler merge old and new values and wait right behind the load) */
     float4 na, nb, nc;
@@ -1324,7 +1344,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_bounce(DevScene S, DevCame
         if (active && !deferred && (parent >> 1) < Wk.cap) {
             /* finished child colour goes straight into the parent's slot */
             const uint32_t pn = parent >> 1;
-            float4 *dst = (parent & 1u) ? Wk.childT : Wk.childR;
+            float4 *dst = (parent & 1u) ? Wk.childT() : Wk.childR();
             dst[pn] = make_float4(leaf[0], leaf[1], leaf[2], 0.0f);
         }
         pc.mark(7);
@@ -1351,7 +1371,7 @@ __device__ __forceinline__ uint32_t fold_values(const float4 A, const float2 K, 
 /* all four loads are issued together (the child slots unconditionally: one round trip, not two) */
 __device__ __forceinline__ uint32_t fold_node(const DevWork &Wk, uint32_t i, float out[3])
 {
-    return fold_values(Wk.nodeA[i], Wk.nodeK[i], Wk.childR[i], Wk.childT[i], out);
+    return fold_values(Wk.nodeA()[i], Wk.nodeK()[i], Wk.childR()[i], Wk.childT()[i], out);
 }
 
 /* k_fold: nodes of `level` (>= 1) -> their parent's child slot */
@@ -1374,7 +1394,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_fold(DevWork Wk, uint32_t level)
         const uint32_t pn = link >> 3;
         if (pn >= Wk.cap)
             continue;
-        float4 *dst = (link & 1u) ? Wk.childT : Wk.childR;
+        float4 *dst = (link & 1u) ? Wk.childT() : Wk.childR();
         dst[pn] = make_float4(c[0], c[1], c[2], 0.0f);
     }
 }
@@ -1405,7 +1425,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DevCamera C, DevWork Wk, D
 #pragma unroll
             for (uint32_t u = 0; u < 4u; ++u) {
                 const uint32_t j = id[u] < Wk.cap ? id[u] : 0u;
-                A[u] = Wk.nodeA[j]; K[u] = Wk.nodeK[j]; cr[u] = Wk.childR[j]; ct[u] = Wk.childT[j];
+                A[u] = Wk.nodeA()[j]; K[u] = Wk.nodeK()[j]; cr[u] = Wk.childR()[j]; ct[u] = Wk.childT()[j];
             }
 #pragma unroll
             for (uint32_t u = 0; u < 4u; ++u) {
