@@ -617,6 +617,18 @@ __device__ __forceinline__ Tables<TABLDS> stage_tables(const DevScene &S, uint32
     }
 }
 
+/* Scene colours every shade needs (background, ambient light), in LDS rather than in scalar registers (the trace
+ * kernels run out of them and spill into VGPR lanes) */
+enum { KC_BG = 0, KC_AMBIENT = 3, KC_WORDS = 8 };
+__device__ __forceinline__ void stage_colours(const DevScene &S, float *kc)
+{
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 3; ++k) {
+            kc[KC_BG + k] = S.bg[k];
+            kc[KC_AMBIENT + k] = S.ambient[k];
+        }
+}
+
 /* counter line of (level, shard): low word = nodes made at `level`, high word = rays queued
  * for level+1 (rt_device.h) */
 __device__ __forceinline__ unsigned long long *level_line(uint32_t *counters, uint32_t level,
@@ -721,7 +733,7 @@ template <bool TILED, bool STATS, bool TABLDS, typename EyeSource>
 __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCamera &C,
                                                 const DevWork &Wk, const float4 *lds_poly,
                                                 float4 *lds_sph, uint32_t *lds_vis, float *lds_park,
-                                                const Tables<TABLDS> &tab, bool hit,
+                                                const float *kc, const Tables<TABLDS> &tab, bool hit,
                                                 const EyeSource &eye_src, float px, float py, float pz,
                                                 uint32_t obj, uint32_t level,
                                                 uint32_t link, uint32_t shard, uint32_t node_base,
@@ -855,9 +867,9 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
         ocg = ((xt % 2) == (yt % 2)) ? 0.0f : 1.0f;
     }
     /* ambient raytrace.c:303-307 */
-    float outr = (ocr * S.ambient[0]) * mA.w;
-    float outg = (ocg * S.ambient[1]) * mA.w;
-    float outb = (ocb * S.ambient[2]) * mA.w;
+    float outr = (ocr * kc[KC_AMBIENT + 0]) * mA.w;
+    float outg = (ocg * kc[KC_AMBIENT + 1]) * mA.w;
+    float outb = (ocb * kc[KC_AMBIENT + 2]) * mA.w;
 
     /* raytrace.c:390-401 */
     outr += (mC.x * dfr) * ocr + (mB.w * spr) * mB.x;
@@ -990,8 +1002,8 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     if (!(hit_r || hit_t)) {
         /* every child (if any) left the scene: the node is finished.  Same expression order as
          * fold_values: local + kr*child, then + kt*child, then the clamp (raytrace.c:440-442,547-549,562) */
-        if (want_r) { outr += kr2 * S.bg[0]; outg += kr2 * S.bg[1]; outb += kr2 * S.bg[2]; }
-        if (want_t) { outr += kt2 * S.bg[0]; outg += kt2 * S.bg[1]; outb += kt2 * S.bg[2]; }
+        if (want_r) { outr += kr2 * kc[KC_BG + 0]; outg += kr2 * kc[KC_BG + 1]; outb += kr2 * kc[KC_BG + 2]; }
+        if (want_t) { outr += kt2 * kc[KC_BG + 0]; outg += kt2 * kc[KC_BG + 1]; outb += kt2 * kc[KC_BG + 2]; }
         leaf[0] = clamp1(outr);
         leaf[1] = clamp1(outg);
         leaf[2] = clamp1(outb);
@@ -1013,7 +1025,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     node_idx = node;
     Wk.nodeA()[node] = make_float4(outr, outg, outb, kr2);
     Wk.nodeK()[node] = make_float2(kt2, __uint_as_float(link | (want_r ? 2u : 0u) | (want_t ? 4u : 0u)));
-    const float4 bg4 = make_float4(S.bg[0], S.bg[1], S.bg[2], 0.0f);
+    const float4 bg4 = make_float4(kc[KC_BG + 0], kc[KC_BG + 1], kc[KC_BG + 2], 0.0f);
     if (want_r && !hit_r)
         Wk.childR()[node] = bg4;
     if (want_t && !hit_t)
@@ -1169,7 +1181,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_primary(DevScene S, DevCam
     uint32_t *lds_vis = (uint32_t *)(lds_sph + sphere_slots(S.nSph));
     const Tables<TABLDS> tab = stage_tables<TABLDS>(S, lds_vis);
     __shared__ float cam[CAM_WORDS];
+    __shared__ float kc[KC_WORDS];
     stage_camera(C, cam);
+    stage_colours(S, kc);
     block_copy(lds_poly, S.poly, S.nPolySlots);
     if (!TILED) {
         block_copy(lds_sph, S.sph, S.nSph);
@@ -1211,12 +1225,12 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_primary(DevScene S, DevCam
             intersect_all<TILED, false, false, STATS>(S, lds_poly, lds_sph, valid, r, RT_NONE, RT_NONE,
                                                       d, obj, tl);
             const bool hit = valid && (obj != RT_NONE);
-            float leaf[3] = {S.bg[0], S.bg[1], S.bg[2]}; /* miss: raytrace.c:700-703 */
+            float leaf[3] = {kc[KC_BG + 0], kc[KC_BG + 1], kc[KC_BG + 2]}; /* miss: raytrace.c:700-703 */
             uint32_t node;
             bool sr, st_;
             const float px = r.ox + r.dx * d, py = r.oy + r.dy * d, pz = r.oz + r.dz * d;
             const PrimaryEye eye_src{cam, fu0, fv0, i, j};
-            const bool deferred = shade_and_spawn<TILED, STATS, TABLDS>(S, C, Wk, lds_poly, lds_sph, lds_vis, lds_park, tab, hit,
+            const bool deferred = shade_and_spawn<TILED, STATS, TABLDS>(S, C, Wk, lds_poly, lds_sph, lds_vis, lds_park, kc, tab, hit,
                                                                 eye_src, px, py, pz, obj, 0u, RT_LINK_NONE << 3, shard,
                                                                 node_base, Wk.capS, leaf, node, sr, st_, tl, pc);
             sc.add(hit, sr, st_);
@@ -1265,6 +1279,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_bounce(DevScene S, DevCame
         return; /* block-uniform */
 
     const Tables<TABLDS> tab = stage_tables<TABLDS>(S, lds_vis);
+    __shared__ float kc[KC_WORDS];
+    stage_colours(S, kc);
     block_copy(lds_poly, S.poly, S.nPolySlots);
     if (!TILED) {
         block_copy(lds_sph, S.sph, S.nSph);
@@ -1330,12 +1346,12 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_bounce(DevScene S, DevCame
         pc.mark(0);
         pc.mark(1);
         const bool hit = active;
-        float leaf[3] = {S.bg[0], S.bg[1], S.bg[2]};
+        float leaf[3] = {kc[KC_BG + 0], kc[KC_BG + 1], kc[KC_BG + 2]};
         uint32_t node;
         bool sr, st_;
         StashedEye::park(lds_eye, r);
         const StashedEye eye_src{lds_eye};
-        const bool deferred = shade_and_spawn<TILED, STATS, TABLDS>(S, C, Wk, lds_poly, lds_sph, lds_vis, lds_park, tab, hit, eye_src,
+        const bool deferred = shade_and_spawn<TILED, STATS, TABLDS>(S, C, Wk, lds_poly, lds_sph, lds_vis, lds_park, kc, tab, hit, eye_src,
                                                             px, py, pz, obj, level,
                                                             ((parent >> 1) << 3) | (parent & 1u), shard, node_base,
                                                             node_room, leaf, node, sr, st_, tl, pc);
