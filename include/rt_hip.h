@@ -251,6 +251,13 @@ int  rt_scene_builtin(rt_scene_t *scene);
  * Returns 1 on success, 0 on failure (reference convention). */
 int  rt_parse_scene(const char *filename, rt_scene_t *scene);
 void rt_scene_free(rt_scene_t *scene);
+/* A loader that really reads the grammar sketched in the reference's `scene` file (scene:1-47;
+ * the reference's parse_scene, scene.c:36-84, tokenises it and throws the tokens away):
+ * desc / camera / world / pointlight / sphere / polygon blocks, '#' comments, material keys
+ * diffuse specular ka kd ks ke kr kt n (grammar in csrc/rt_host.c).  Camera basis per
+ * scene.c:236-258.  Returns 1 on success, 0 on failure with a message on stdout (the reference's
+ * convention, scene.c:31-35); release with rt_scene_free. */
+int  rt_load_scene(const char *filename, rt_scene_t *scene);
 
 /* Seeded synthetic scenes of BASELINE configs 4/5: nSpheres random
  * spheres + nPolys (0..4) axis-aligned quads + nLights lights; SplitMix64 generator.

@@ -15,7 +15,7 @@ EXPORTS = [
     "rt_hip_scene_upload", "rt_hip_render_rows", "rt_hip_render_interleaved", "rt_hip_finish", "rt_hip_render_stats",
     "rt_hip_ctx_set_timing", "rt_hip_ctx_set_batch_samples", "rt_hip_last_error", "rt_hip_version",
     "rt_poly_plane", "rt_scene_builtin", "rt_parse_scene", "rt_scene_free", "rt_scene_synthetic",
-    "rt_write_image", "write_image", "rt_hip_selftest_arith",
+    "rt_write_image", "write_image", "rt_hip_selftest_arith", "rt_load_scene",
 ]
 
 _lib = None
@@ -70,6 +70,8 @@ def load():
     lib.rt_scene_builtin.restype = i32
     lib.rt_parse_scene.argtypes = [C.c_char_p, P(A.rt_scene_t)]
     lib.rt_parse_scene.restype = i32
+    lib.rt_load_scene.argtypes = [C.c_char_p, P(A.rt_scene_t)]
+    lib.rt_load_scene.restype = i32
     lib.rt_scene_free.argtypes = [P(A.rt_scene_t)]
     lib.rt_scene_free.restype = None
     lib.rt_scene_synthetic.argtypes = [P(A.rt_scene_t), u64, u32, u32, u32, i32]

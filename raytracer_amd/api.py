@@ -5,6 +5,7 @@ write_image (output.h:15-16).  Everything computes through librt_hip.so (HIP ker
 here renders on the CPU.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -48,6 +49,15 @@ class Scene:
             self.free()
         except Exception:
             pass
+
+
+def load_scene(filename):
+    """rt_load_scene: really reads the grammar of the reference's `scene` file."""
+    s = Scene()
+    if not load().rt_load_scene(os.fsencode(filename), C.byref(s.c)):
+        raise ValueError(f"rt_load_scene: cannot load {filename!r} (the reason was printed to stdout)")
+    s._owned = True
+    return s
 
 
 def parse_scene(filename):

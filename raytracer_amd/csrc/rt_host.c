@@ -227,6 +227,298 @@ void rt_scene_free(rt_scene_t *s)
     s->nObjects = s->nLights = 0;
 }
 
+/* ---- scene-file loader ------------------------------------- */
+/*
+ * The reference ships a `scene` file whose grammar its parse_scene never interprets
+ * (scene.c:36-84 reads tokens and drops them).  rt_load_scene reads that grammar for real:
+ *
+ *   desc       { <objects> <lights> }                     advisory counts, checked when present
+ *   camera     { position x y z   lookat x y z   upvector x y z   projection fov near far }
+ *   world      { ambient r g b   background r g b }       (extension; defaults = builtin scene)
+ *   pointlight { position x y z   diffuse r g b   range r }
+ *   sphere     { name s   position x y z   radius r   <material keys> }
+ *   polygon    { name s   point x y z  (3 or more)    <material keys> }
+ *   material keys: diffuse r g b | specular r g b | ka v | kd v | ks v | ke v | kr v | kt v | n v
+ *   '#' starts a comment; numbers may carry a C 'f' suffix (the reference's file has "1.0f").
+ *
+ * Camera basis as scene.c:236-258: N = normalize(lookat - position), V = upvector as given (not
+ * re-orthogonalised), U = N x V.  `projection` is parsed and validated but not stored: fovY / near
+ * are arguments of raytrace() (main.c:159-160), not fields of scene_t.
+ * Names live in the same allocation as the object array, so rt_scene_free releases them.
+ */
+typedef struct {
+    FILE *fp;
+    const char *file;
+    int line;
+    char tok[256];
+} rt_lexer;
+
+static int lex_next(rt_lexer *lx)
+{
+    int ch;
+    for (;;) {
+        ch = fgetc(lx->fp);
+        if (ch == EOF)
+            return 0;
+        if (ch == '\n')
+            lx->line++;
+        if (ch == '#') {
+            while ((ch = fgetc(lx->fp)) != EOF && ch != '\n')
+                ;
+            lx->line++;
+            continue;
+        }
+        if (ch == ' ' || ch == '\t' || ch == '\r' || ch == '\n')
+            continue;
+        break;
+    }
+    size_t n = 0;
+    if (ch == '{' || ch == '}') {
+        lx->tok[n++] = (char)ch;
+    } else {
+        while (ch != EOF && ch != ' ' && ch != '\t' && ch != '\r' && ch != '\n' && ch != '{' && ch != '}' &&
+               ch != '#') {
+            if (n + 1 < sizeof lx->tok)
+                lx->tok[n++] = (char)ch;
+            ch = fgetc(lx->fp);
+        }
+        if (ch != EOF)
+            ungetc(ch, lx->fp);
+    }
+    lx->tok[n] = 0;
+    return 1;
+}
+
+static int lex_fail(const rt_lexer *lx, const char *what)
+{
+    printf("Error parsing scene file {%s} line %d: %s (at \"%s\").\n", lx->file, lx->line, what, lx->tok);
+    fflush(stdout);
+    return 0;
+}
+
+static int lex_floats(rt_lexer *lx, float *out, int n)
+{
+    for (int i = 0; i < n; ++i) {
+        if (!lex_next(lx))
+            return lex_fail(lx, "number expected, file ends");
+        char *end = NULL;
+        out[i] = strtof(lx->tok, &end);
+        if (end == lx->tok || !(end[0] == 0 || ((end[0] == 'f' || end[0] == 'F') && end[1] == 0)))
+            return lex_fail(lx, "number expected");
+    }
+    return 1;
+}
+
+typedef struct {
+    rt_object3d obj;
+    char name[64];
+    float (*pts)[3];
+    uint32_t npts, cap;
+} rt_parsed_obj;
+
+static int parse_material_key(rt_lexer *lx, rt_material *m, int *known)
+{
+    float v[3];
+    *known = 1;
+    if (!strcmp(lx->tok, "diffuse")) {
+        if (!lex_floats(lx, v, 3)) return 0;
+        set_color(&m->colors[RT_MATERIAL_DIFFUSECOLOR], v[0], v[1], v[2]);
+    } else if (!strcmp(lx->tok, "specular")) {
+        if (!lex_floats(lx, v, 3)) return 0;
+        set_color(&m->colors[RT_MATERIAL_SPECULARCOLOR], v[0], v[1], v[2]);
+    } else if (!strcmp(lx->tok, "ka")) { if (!lex_floats(lx, &m->phong_ka, 1)) return 0;
+    } else if (!strcmp(lx->tok, "kd")) { if (!lex_floats(lx, &m->phong_kd, 1)) return 0;
+    } else if (!strcmp(lx->tok, "ks")) { if (!lex_floats(lx, &m->phong_ks, 1)) return 0;
+    } else if (!strcmp(lx->tok, "ke")) { if (!lex_floats(lx, &m->phong_ke, 1)) return 0;
+    } else if (!strcmp(lx->tok, "kr")) { if (!lex_floats(lx, &m->kr, 1)) return 0;
+    } else if (!strcmp(lx->tok, "kt")) { if (!lex_floats(lx, &m->kt, 1)) return 0;
+    } else if (!strcmp(lx->tok, "n")) {  if (!lex_floats(lx, &m->n, 1)) return 0;
+    } else {
+        *known = 0;
+    }
+    return 1;
+}
+
+int rt_load_scene(const char *filename, rt_scene_t *scene)
+{
+    rt_lexer lx;
+    memset(&lx, 0, sizeof lx);
+    lx.fp = fopen(filename, "r");
+    lx.file = filename;
+    lx.line = 1;
+    if (!lx.fp) {
+        printf("Error opening file {%s} for reading.\n", filename);
+        return 0;
+    }
+    scene_common(scene);
+    float eye[3] = {scene->eyePos.x, scene->eyePos.y, scene->eyePos.z};
+    float look[3] = {scene->lookAt.x, scene->lookAt.y, scene->lookAt.z};
+    float up[3] = {0.0f, 1.0f, 0.0f};
+    rt_parsed_obj *objs = NULL;
+    rt_pointlight *lights = NULL;
+    uint32_t nobj = 0, cobj = 0, nlight = 0, clight = 0;
+    long want_obj = -1, want_light = -1;
+    int ok = 1;
+
+    while (ok && lex_next(&lx)) {
+        char block[32];
+        snprintf(block, sizeof block, "%.31s", lx.tok);
+        if (!lex_next(&lx) || strcmp(lx.tok, "{")) { ok = lex_fail(&lx, "'{' expected after block name"); break; }
+        if (!strcmp(block, "desc")) {
+            float v[2];
+            if (!(ok = lex_floats(&lx, v, 2))) break;
+            want_obj = (long)v[0];
+            want_light = (long)v[1];
+            if (!lex_next(&lx) || strcmp(lx.tok, "}")) { ok = lex_fail(&lx, "'}' expected"); break; }
+            continue;
+        }
+        rt_parsed_obj *po = NULL;
+        rt_pointlight *pl = NULL;
+        const int is_sphere = !strcmp(block, "sphere"), is_poly = !strcmp(block, "polygon");
+        const int is_light = !strcmp(block, "pointlight"), is_cam = !strcmp(block, "camera");
+        const int is_world = !strcmp(block, "world");
+        if (is_sphere || is_poly) {
+            if (nobj == cobj) {
+                cobj = cobj ? 2 * cobj : 16;
+                rt_parsed_obj *g = (rt_parsed_obj *)realloc(objs, cobj * sizeof *objs);
+                if (!g) { ok = lex_fail(&lx, "out of memory"); break; }
+                objs = g;
+            }
+            po = &objs[nobj++];
+            memset(po, 0, sizeof *po);
+            po->obj.geometryType = is_sphere ? RT_GEOMETRY_SPHERE : RT_GEOMETRY_POLYGON;
+            po->obj.sphr_obj.center.w = 1.0f;
+            /* the floor's material of the builtin scene is the default */
+            set_material(&po->obj.material, 0.5f, 0.5f, 0.5f, 0.1f, 0.7f, 0.2f, 2.0f, 0.0f, 0.0f, 1.0f);
+        } else if (is_light) {
+            if (nlight == clight) {
+                clight = clight ? 2 * clight : 8;
+                rt_pointlight *g = (rt_pointlight *)realloc(lights, clight * sizeof *lights);
+                if (!g) { ok = lex_fail(&lx, "out of memory"); break; }
+                lights = g;
+            }
+            pl = &lights[nlight++];
+            memset(pl, 0, sizeof *pl);
+            set_vec(&pl->position, 0.0f, 0.0f, 0.0f, 1.0f);
+            set_color(&pl->color, 1.0f, 1.0f, 1.0f);
+            pl->range = 150.0f;
+        } else if (!is_cam && !is_world) {
+            ok = lex_fail(&lx, "unknown block");
+            break;
+        }
+        for (;;) { /* keys of the block */
+            if (!lex_next(&lx)) { ok = lex_fail(&lx, "'}' expected, file ends"); break; }
+            if (!strcmp(lx.tok, "}"))
+                break;
+            float v[3];
+            int known = 0;
+            if (po) {
+                if (!(ok = parse_material_key(&lx, &po->obj.material, &known))) break;
+                if (known) continue;
+                if (!strcmp(lx.tok, "name")) {
+                    if (!lex_next(&lx)) { ok = lex_fail(&lx, "name expected"); break; }
+                    snprintf(po->name, sizeof po->name, "%.63s", lx.tok);
+                } else if (is_sphere && !strcmp(lx.tok, "position")) {
+                    if (!(ok = lex_floats(&lx, v, 3))) break;
+                    set_vec(&po->obj.sphr_obj.center, v[0], v[1], v[2], 1.0f);
+                } else if (is_sphere && !strcmp(lx.tok, "radius")) {
+                    if (!(ok = lex_floats(&lx, &po->obj.sphr_obj.radius, 1))) break;
+                } else if (is_poly && !strcmp(lx.tok, "point")) {
+                    if (!(ok = lex_floats(&lx, v, 3))) break;
+                    if (po->npts == po->cap) {
+                        po->cap = po->cap ? 2 * po->cap : 8;
+                        float(*g)[3] = (float(*)[3])realloc(po->pts, po->cap * sizeof *po->pts);
+                        if (!g) { ok = lex_fail(&lx, "out of memory"); break; }
+                        po->pts = g;
+                    }
+                    memcpy(po->pts[po->npts++], v, sizeof v);
+                } else { ok = lex_fail(&lx, "unknown key"); break; }
+            } else if (pl) {
+                if (!strcmp(lx.tok, "position")) {
+                    if (!(ok = lex_floats(&lx, v, 3))) break;
+                    set_vec(&pl->position, v[0], v[1], v[2], 1.0f);
+                } else if (!strcmp(lx.tok, "diffuse")) {
+                    if (!(ok = lex_floats(&lx, v, 3))) break;
+                    set_color(&pl->color, v[0], v[1], v[2]);
+                } else if (!strcmp(lx.tok, "range")) {
+                    if (!(ok = lex_floats(&lx, &pl->range, 1))) break;
+                } else { ok = lex_fail(&lx, "unknown key"); break; }
+            } else if (is_cam) {
+                if (!strcmp(lx.tok, "position")) { if (!(ok = lex_floats(&lx, eye, 3))) break;
+                } else if (!strcmp(lx.tok, "lookat")) { if (!(ok = lex_floats(&lx, look, 3))) break;
+                } else if (!strcmp(lx.tok, "upvector")) { if (!(ok = lex_floats(&lx, up, 3))) break;
+                } else if (!strcmp(lx.tok, "projection")) {
+                    if (!(ok = lex_floats(&lx, v, 3))) break;
+                    if (!(v[0] > 0.0f && v[0] < 180.0f && v[1] > 0.0f)) { ok = lex_fail(&lx, "bad projection"); break; }
+                } else { ok = lex_fail(&lx, "unknown key"); break; }
+            } else { /* world */
+                if (!strcmp(lx.tok, "ambient")) {
+                    if (!(ok = lex_floats(&lx, v, 3))) break;
+                    set_color(&scene->ambientLightColor, v[0], v[1], v[2]);
+                } else if (!strcmp(lx.tok, "background")) {
+                    if (!(ok = lex_floats(&lx, v, 3))) break;
+                    set_color(&scene->bgColor, v[0], v[1], v[2]);
+                } else { ok = lex_fail(&lx, "unknown key"); break; }
+            }
+        }
+        if (ok && is_poly && po->npts < 3)
+            ok = lex_fail(&lx, "a polygon needs at least three points");
+    }
+    fclose(lx.fp);
+    if (ok && want_obj >= 0 && ((long)nobj != want_obj || (long)nlight != want_light)) {
+        printf("Error parsing scene file {%s}: desc announces %ld objects and %ld lights, found %u and %u.\n",
+               filename, want_obj, want_light, nobj, nlight);
+        fflush(stdout);
+        ok = 0;
+    }
+
+    if (ok) { /* camera: scene.c:236-258 */
+        set_vec(&scene->eyePos, eye[0], eye[1], eye[2], 1.0f);
+        set_vec(&scene->lookAt, look[0], look[1], look[2], 0.0f);
+        set_vec(&scene->upVec, up[0], up[1], up[2], 1.0f);
+        float nx = look[0] - eye[0], ny = look[1] - eye[1], nz = look[2] - eye[2];
+        normalize3(&nx, &ny, &nz);
+        set_vec(&scene->N, nx, ny, nz, 0.0f);
+        scene->V = scene->upVec;
+        set_vec(&scene->U, scene->N.y * scene->V.z - scene->N.z * scene->V.y,
+                scene->N.z * scene->V.x - scene->N.x * scene->V.z,
+                scene->N.x * scene->V.y - scene->N.y * scene->V.x, 0.0f);
+        /* objects + their names in one allocation; vertices per polygon (rt_scene_free) */
+        const size_t names = (size_t)nobj * sizeof objs[0].name;
+        scene->objects = (rt_object3d *)calloc(1, (nobj ? nobj : 1) * sizeof(rt_object3d) + names);
+        scene->lights = (rt_pointlight *)calloc(nlight ? nlight : 1, sizeof(rt_pointlight));
+        if (!scene->objects || !scene->lights)
+            ok = 0;
+        for (uint32_t i = 0; ok && i < nobj; ++i) {
+            rt_object3d *o = &scene->objects[i];
+            *o = objs[i].obj;
+            char *nm = (char *)(scene->objects + nobj) + (size_t)i * sizeof objs[0].name;
+            memcpy(nm, objs[i].name, sizeof objs[0].name);
+            o->debugName = nm;
+            if (o->geometryType == RT_GEOMETRY_POLYGON) {
+                o->poly_obj.nVerticies = objs[i].npts;
+                o->poly_obj.vertex = (rt_vec4 *)malloc(objs[i].npts * sizeof(rt_vec4));
+                if (!o->poly_obj.vertex) { ok = 0; break; }
+                for (uint32_t k = 0; k < objs[i].npts; ++k)
+                    set_vec(&o->poly_obj.vertex[k], objs[i].pts[k][0], objs[i].pts[k][1], objs[i].pts[k][2], 1.0f);
+                rt_poly_plane(&o->poly_obj.plane, &o->poly_obj);
+            }
+            scene->nObjects = i + 1; /* what rt_scene_free must walk if a later allocation fails */
+        }
+        if (ok) {
+            memcpy(scene->lights, lights, nlight * sizeof *lights);
+            scene->nLights = nlight;
+        }
+    }
+    for (uint32_t i = 0; i < nobj; ++i)
+        free(objs[i].pts);
+    free(objs);
+    free(lights);
+    if (!ok)
+        rt_scene_free(scene);
+    return ok;
+}
+
 /* ---- seeded synthetic scenes (BASELINE configs 4 and 5) --------- */
 
 static uint64_t splitmix64(uint64_t *state)

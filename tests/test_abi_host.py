@@ -186,3 +186,67 @@ def test_product_package_never_touches_the_oracle():
                 assert "oracle" not in text.lower(), f"{fn} mentions the oracle"
     out = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in out and "libref" not in out
+
+
+def _scene_bytes(sc):
+    """Everything of an rt_scene_t that is data (pointers and names left out)."""
+    c = sc.c
+    parts = [bytes(c)[:C.sizeof(A.rt_scene_t) - 16]]         # up to the two array pointers
+    for i in range(c.nObjects):
+        o = c.objects[i]
+        parts.append(bytes(o.material))
+        parts.append(bytes([o.geometryType & 0xFF]))
+        if o.geometryType == 1:
+            parts.append(bytes(o.sphr_obj))
+        else:
+            p = o.poly_obj
+            parts.append(bytes(p.plane))
+            parts.append(bytes(C.string_at(p.vertex, p.nVerticies * 16)))
+    for i in range(c.nLights):
+        parts.append(bytes(c.lights[i]))
+    return b"".join(parts)
+
+
+def test_scene_file_loader_reproduces_the_builtin_scene():
+    """rt_load_scene really reads the grammar of the reference's `scene` file.
+    tests/golden/whitted.scene states the hard-coded scene in that grammar; loading it must give the
+    very bytes rt_scene_builtin() (= the reference's parse_scene, checked above) builds.  The reference
+    itself never interprets the file, so beyond this equality the loader is 'parity unpinned'."""
+    got = rt.load_scene(os.path.join(ROOT, "tests", "golden", "whitted.scene"))
+    want = rt.Scene.builtin()
+    assert (got.c.nObjects, got.c.nLights) == (3, 1)
+    assert _scene_bytes(got) == _scene_bytes(want)
+    assert got.c.objects[0].debugName == b"Sphere_1" and got.c.objects[2].debugName == b"Floor"
+    got.free()
+
+
+def test_scene_file_loader_grammar_and_errors(tmp_path, capfd):
+    def load(text):
+        f = tmp_path / "s.scene"
+        f.write_text(text)
+        return rt.load_scene(str(f))
+
+    # the shape of the reference's own file: no material keys, no world block, '#' comments, 1.0f
+    sc = load("desc { 2 1 }\ncamera { position 0 4.5 0 lookat 0 0 0 upvector 0 1 0 projection 45.0 1.0 1000.0 }\n"
+              "pointlight { position 1 8 1 diffuse 1.0 1.0 1.0 }\n"
+              "sphere { name s1 position 0 -5 -6 radius 1.15 diffuse 1.0 0.0 0.0 } # red\n"
+              "polygon { name p point 7 0 0 point 7 0 -100 point -15 0 -100 point -15 0 0 diffuse .5 .5 1.0f }\n")
+    c = sc.c
+    assert (c.nObjects, c.nLights) == (2, 1)
+    # camera basis as scene.c:236-258: N = normalize(lookat - position) = (0,-1,0); V = up; U = N x V = 0
+    assert (c.N.x, c.N.y, c.N.z) == (0.0, -1.0, 0.0) and (c.V.x, c.V.y, c.V.z) == (0.0, 1.0, 0.0)
+    assert (c.U.x, c.U.y, c.U.z) == (0.0, 0.0, 0.0)
+    assert c.objects[0].geometryType == 1 and abs(c.objects[0].sphr_obj.radius - 1.15) < 1e-7
+    assert c.objects[1].poly_obj.nVerticies == 4 and c.objects[1].poly_obj.plane.B == 1.0
+    m = c.objects[0].material                                   # defaults = the builtin floor's material
+    assert (m.phong_ka, m.kr, m.kt, m.n) == (np.float32(0.1), 0.0, 0.0, 1.0)
+    assert c.lights[0].range == 150.0
+    sc.free()
+    for bad, why in [("sphere { radius }", "number expected"), ("sphere { colour 1 2 3 }", "unknown key"),
+                     ("torus { }", "unknown block"), ("polygon { point 0 0 0 point 1 0 0 }", "at least three"),
+                     ("desc { 1 0 }", "announces"), ("sphere { radius 1", "file ends"), ("sphere radius", "'{' expected")]:
+        with pytest.raises(ValueError):
+            load(bad)
+        assert why in capfd.readouterr().out
+    with pytest.raises(ValueError):
+        rt.load_scene(str(tmp_path / "missing"))
