@@ -113,12 +113,21 @@ def main():
     ap.add_argument("--overlap", action="store_true",
                     help="give every in-flight frame its own stream (kernels of neighbouring frames overlap; the "
                          "event-timed k_primary duration then includes the sharing and is not a clean roofline input)")
+    ap.add_argument("--gather-stream", choices=["side", "same"], default="same",
+                    help="N > 1: run the all-gather + de-interleave on the render stream, or on a second stream "
+                         "behind events (overlaps the next frame's render, but every cross-stream hand-over costs "
+                         "~0.1 ms of queue latency on this runtime: measured slower in the one-GPU rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # rehearsal of one rank of an N-GPU run on a single GPU (no process group: the gather becomes a
+    # local copy into this rank's slot); the printed line is marked and is not a scaling result
+    fake = int(os.environ.get("RT_BENCH_REHEARSE_WORLD", "0"))
+    if fake > 1 and world == 1:
+        world, rank, args.gpus = fake, int(os.environ.get("RT_BENCH_REHEARSE_RANK", "0")), fake
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
@@ -126,7 +135,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 and not fake:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -148,7 +157,14 @@ def main():
         c.upload(scene)
         ctxs.append(c)
         streams.append(torch.cuda.Stream(device=dev) if args.overlap else shared)
-        gathers.append(FrameGather(plan, W, torch.int32, dev))  # 0xFFRRGGBB bit patterns
+        gathers.append(FrameGather(plan, W, torch.int32, dev, rank=rank))  # 0xFFRRGGBB bit patterns
+
+    # N > 1: the in-place all-gather of frame k and its de-interleave copy (the library's streaming
+    # kernel) follow the render on the same stream; --gather-stream side moves them behind an event
+    # onto a second stream so that they overlap frame k+1.
+    comm = (torch.cuda.Stream(device=dev) if args.gather_stream == "side" else shared) if world > 1 else None
+    rendered = [torch.cuda.Event() for _ in range(inflight)]
+    gathered = [torch.cuda.Event() for _ in range(inflight)]
 
     def submit(i):
         k = i % inflight
@@ -156,9 +172,15 @@ def main():
         with torch.cuda.stream(st):
             if world == 1:
                 ctx.render_rows(cam, fg.frame.data_ptr(), 0, 0, H, st.cuda_stream)
-            else:
-                ctx.render_interleaved(cam, fg.local.data_ptr(), 0, rank, world, st.cuda_stream)
-                fg.gather()  # RCCL all-gather of the local slices + de-interleave copy, same stream
+                return
+            if i >= inflight:
+                st.wait_event(gathered[k])  # the previous gather out of this frame's buffers is done
+            ctx.render_interleaved(cam, fg.local.data_ptr(), 0, rank, world, st.cuda_stream)
+            rendered[k].record(st)
+        with torch.cuda.stream(comm):
+            comm.wait_event(rendered[k])
+            fg.gather(collective=not fake)  # in-place RCCL all-gather of the local slices + de-interleave
+            gathered[k].record(comm)
 
     def collect(i):
         k = i % inflight
@@ -170,10 +192,15 @@ def main():
     if world == 1:
         st_alg = ctxs[0].render_stats(cam, gathers[0].frame.data_ptr(), 0, 0, H, 0).as_dict()
     else:
-        # the instrumented kernels render contiguous rows; use a slab with this rank's share of rows
-        rows = H // world
+        # the instrumented kernels render contiguous rows: add up this rank's own 8-row blocks (a slab
+        # would not do - the top slab is all sky while the timed cyclic blocks are a fair sample)
         full = torch.zeros((H, W), dtype=torch.int32, device=dev)
-        st_alg = ctxs[0].render_stats(cam, full.data_ptr(), 0, rank * rows, rows, 0).as_dict()
+        st_alg = {}
+        for y, n, _ in plan.rows_of(rank):
+            d = ctxs[0].render_stats(cam, full.data_ptr(), 0, y, n, 0).as_dict()
+            for k, v in d.items():
+                if isinstance(v, (int, float)):
+                    st_alg[k] = st_alg.get(k, 0) + v
         del full
     del tmp
     my_rows = sum(n for _, n, _ in plan.rows_of(rank)) if world > 1 else H
@@ -183,7 +210,7 @@ def main():
         collect(i)
     for c in ctxs:
         c.set_timing(True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -201,14 +228,14 @@ def main():
         k0_n += st.k0_launches
         rays_rank += (st.primary_rays + st.shadow_rays + st.reflection_rays + st.transmission_rays)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
     for c in ctxs:
         c.set_timing(False)
 
     tot = torch.tensor([dt, float(rays_rank)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist is not None:
         tmax = tot.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -217,7 +244,7 @@ def main():
         dt_max, rays_all = dt, float(rays_rank)
 
     if rank == 0:
-        samples = W * (H // world) * sqrt_spp * sqrt_spp
+        samples = W * my_rows * sqrt_spp * sqrt_spp
         flops_k0 = algorithmic_flops_k0(st_alg, samples, scene.c.nLights)
         k0_avg_ms = k0_ms / max(k0_n, 1)
         launches_per_step = k0_n / max(args.steps, 1)
@@ -234,7 +261,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (the reference's hard-coded Whitted scene, scene.c:86-258)",
+            "data": "synthetic (the reference's hard-coded Whitted scene, scene.c:86-258)"
+                    + (f"; REHEARSAL of rank {rank} of {world} on one GPU, no collective" if fake else ""),
             "config": {"workload": f"builtin Whitted scene {W}x{H}, sqrtSpp {sqrt_spp} ({sqrt_spp * sqrt_spp} spp), "
                                    f"depth {depth}" + ("" if world == 1 else f", cyclic 8-row blocks over {world} GPUs + RCCL all-gather"),
                        "rays_per_step": rays_all / args.steps,
@@ -252,7 +280,7 @@ def main():
         print(json.dumps(out), flush=True)
     for c in ctxs:
         c.close()
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -211,6 +211,13 @@ int  rt_hip_render_interleaved(rt_hip_ctx *ctx, const rt_camera *camera,
                                uint32_t *d_argb_local, float *d_radiance_local,
                                uint32_t phase, uint32_t nphases, void *stream);
 
+/* After the all-gather of the ranks' compact buffers (rank r's buffer at rows [r*L, (r+1)*L) of
+ * d_gathered, L = 8*ceil(ceil(H/8)/nphases) rows of `width` pixels): one streaming copy that puts
+ * block k of rank r at frame block k*nphases + r.  d_frame holds height rows.  No counterpart in the
+ * reference (its Cell host copies pixel by pixel, ppu/ppu_raytrace.c:312-338).  Asynchronous. */
+int  rt_hip_deinterleave(const uint32_t *d_gathered, uint32_t *d_frame, uint32_t width, uint32_t height,
+                         uint32_t nphases, void *stream);
+
 /* Wait for the last rt_hip_render_rows, verify no queue overflowed (re-rendering finer
  * batches if one did) and return its counters.  stats may be NULL. */
 int  rt_hip_finish(rt_hip_ctx *ctx, rt_hip_stats *stats);

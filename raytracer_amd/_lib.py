@@ -15,7 +15,7 @@ EXPORTS = [
     "rt_hip_scene_upload", "rt_hip_render_rows", "rt_hip_render_interleaved", "rt_hip_finish", "rt_hip_render_stats",
     "rt_hip_ctx_set_timing", "rt_hip_ctx_set_batch_samples", "rt_hip_last_error", "rt_hip_version",
     "rt_poly_plane", "rt_scene_builtin", "rt_parse_scene", "rt_scene_free", "rt_scene_synthetic",
-    "rt_write_image", "write_image", "rt_hip_selftest_arith", "rt_load_scene",
+    "rt_write_image", "write_image", "rt_hip_selftest_arith", "rt_load_scene", "rt_hip_deinterleave",
 ]
 
 _lib = None
@@ -52,6 +52,8 @@ def load():
     lib.rt_hip_render_rows.restype = i32
     lib.rt_hip_render_interleaved.argtypes = [vp, P(A.rt_camera), vp, vp, u32, u32, vp]
     lib.rt_hip_render_interleaved.restype = i32
+    lib.rt_hip_deinterleave.argtypes = [vp, vp, u32, u32, u32, vp]
+    lib.rt_hip_deinterleave.restype = i32
     lib.rt_hip_finish.argtypes = [vp, P(A.rt_hip_stats)]
     lib.rt_hip_finish.restype = i32
     lib.rt_hip_render_stats.argtypes = [vp, P(A.rt_camera), vp, vp, u32, u32, vp, P(A.rt_hip_stats)]

@@ -399,8 +399,10 @@ int check_args(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb, uint32_t r
 
 uint64_t default_batch_samples(const rt_hip_ctx *c)
 {
-    /* every sample can become one root node and two level-1 rays */
-    uint64_t m = c->cap / 2;
+    /* A sample makes at most one root node, and its children queue at most two level-1 hits; scenes
+     * in which more than half the samples queue two hits are rare, and a batch that does outgrow
+     * the queues is split and rendered again (drain), so the plan is one sample per entry. */
+    uint64_t m = c->cap;
     if (c->batch_samples && c->batch_samples < m)
         m = c->batch_samples;
     return m ? m : 1;
@@ -419,6 +421,18 @@ extern "C" {
 
 const char *rt_hip_last_error(void) { return g_err; }
 const char *rt_hip_version(void) { return "rt_hip 0.1 (gfx950)"; }
+
+int rt_hip_deinterleave(const uint32_t *d_gathered, uint32_t *d_frame, uint32_t width, uint32_t height,
+                        uint32_t nphases, void *stream)
+{
+    if (!d_gathered || !d_frame || !nphases) {
+        set_err("null argument");
+        return RT_E_INVALID;
+    }
+    rt_launch_deinterleave(d_gathered, d_frame, width, height, nphases, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 
 int rt_hip_selftest_arith(const float *d_a, const float *d_b, const float *d_c, uint32_t n, float *d_out,
                           double *d_out64, void *stream)

@@ -167,5 +167,7 @@ void rt_launch_fold(const DevWork &Wk, uint32_t level, uint32_t expect, hipStrea
 void rt_launch_resolve(const DevCamera &C, const DevWork &Wk, const DevRows &R, uint32_t *d_argb,
                        float *d_radiance, hipStream_t stream);
 size_t rt_scene_lds_bytes(const DevScene &S);
+void rt_launch_deinterleave(const uint32_t *gathered, uint32_t *frame, uint32_t width, uint32_t height,
+                            uint32_t nphases, hipStream_t stream);
 void rt_launch_selftest_arith(const float *a, const float *b, const float *c, uint32_t n, float *out,
                               double *out64, hipStream_t stream);

@@ -1465,6 +1465,22 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DevCamera C, DevWork Wk, D
     }
 }
 
+/* rt_hip_deinterleave: frame row y = block b*8 + line; b = k*nphases + r lives at gathered row
+ * (r*blocks_per_rank + k)*8 + line.  One thread per 16 bytes when the width allows, else per pixel. */
+template <typename T>
+__global__ __launch_bounds__(RT_BLOCK) void k_deinterleave(const T *gathered, T *frame, uint32_t row_words,
+                                                           uint32_t height, uint32_t nphases,
+                                                           uint32_t blocks_per_rank)
+{
+    const size_t total = (size_t)height * row_words;
+    for (size_t i = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x; i < total; i += (size_t)gridDim.x * RT_BLOCK) {
+        const uint32_t y = (uint32_t)(i / row_words), x = (uint32_t)(i % row_words);
+        const uint32_t b = y >> 3, line = y & 7u;
+        const uint32_t r = b % nphases, k = b / nphases;
+        frame[i] = gathered[((size_t)(r * blocks_per_rank + k) * 8u + line) * row_words + x];
+    }
+}
+
 /* rt_hip_selftest_arith: the helpers of rt_arith.h as the kernels use them */
 __global__ __launch_bounds__(RT_BLOCK) void k_selftest_arith(const float *a, const float *b, const float *c,
                                                              uint32_t n, float *out, double *out64)
@@ -1590,4 +1606,24 @@ void rt_launch_selftest_arith(const float *a, const float *b, const float *c, ui
 {
     if (n)
         k_selftest_arith<<<(n + RT_BLOCK - 1) / RT_BLOCK, RT_BLOCK, 0, stream>>>(a, b, c, n, out, out64);
+}
+
+void rt_launch_deinterleave(const uint32_t *gathered, uint32_t *frame, uint32_t width, uint32_t height,
+                            uint32_t nphases, hipStream_t stream)
+{
+    const uint32_t blocks_per_rank = ((height + 7u) / 8u + nphases - 1u) / nphases;
+    const bool wide = (width % 4u) == 0 && ((uintptr_t)gathered % 16u) == 0 && ((uintptr_t)frame % 16u) == 0;
+    const uint32_t row_words = wide ? width / 4u : width;
+    const size_t total = (size_t)height * row_words;
+    if (!total)
+        return;
+    size_t grid = (total + RT_BLOCK - 1) / RT_BLOCK;
+    if (grid > 8192)
+        grid = 8192;
+    if (wide)
+        k_deinterleave<uint4><<<(uint32_t)grid, RT_BLOCK, 0, stream>>>((const uint4 *)gathered, (uint4 *)frame,
+                                                                        row_words, height, nphases, blocks_per_rank);
+    else
+        k_deinterleave<uint32_t><<<(uint32_t)grid, RT_BLOCK, 0, stream>>>(gathered, frame, row_words, height,
+                                                                           nphases, blocks_per_rank);
 }

@@ -61,17 +61,30 @@ def deinterleave(gathered, plan, out=None):
 class FrameGather:
     """Pre-allocated buffers for `all-gather the local slices, de-interleave into the frame`."""
 
-    def __init__(self, plan, width, dtype, device, trailing=()):
+    def __init__(self, plan, width, dtype, device, trailing=(), rank=0):
         self.plan = plan
+        self.width = width
         shape_tail = (width,) + tuple(trailing)
-        self.local = torch.zeros((plan.local_rows,) + shape_tail, dtype=dtype, device=device)
         self.gathered = torch.zeros((plan.world * plan.local_rows,) + shape_tail, dtype=dtype, device=device)
+        # this rank's slice of the gathered buffer IS its render target: the all-gather is in place
+        self.local = self.gathered[rank * plan.local_rows:(rank + 1) * plan.local_rows]
         self.frame = torch.zeros((plan.height,) + shape_tail, dtype=dtype, device=device)
+        # 32-bit pixel frames on the GPU are de-interleaved by the library's streaming kernel
+        self._native = (self.gathered.is_cuda and not trailing and self.gathered.element_size() == 4)
 
-    def gather(self, group=None):
+    def gather(self, group=None, collective=True):
         import torch.distributed as dist
-        if self.plan.world == 1:
-            self.gathered.copy_(self.local)
-        else:
-            dist.all_gather_into_tensor(self.gathered.view(-1), self.local.view(-1), group=group)
+        if self.plan.world > 1 and collective:
+            dist.all_gather_into_tensor(self.gathered.view(-1), self.local.reshape(-1), group=group)
+        return self.rebuild()
+
+    def rebuild(self):
+        """gathered -> frame on the current stream"""
+        if self._native:
+            from . import _lib
+            st = torch.cuda.current_stream(self.gathered.device).cuda_stream
+            _lib.check(_lib.load().rt_hip_deinterleave(self.gathered.data_ptr(), self.frame.data_ptr(), self.width,
+                                                       self.plan.height, self.plan.world, st),
+                       "rt_hip_deinterleave")
+            return self.frame
         return deinterleave(self.gathered, self.plan, out=self.frame)

@@ -33,8 +33,8 @@ def _worker(rank, world, port, W, H, spp, depth, outdir):
     sc = rt.Scene.builtin()
     cam = O.prepare_camera(sc.c, W, H, spp, depth)
     plan = RowPlan(H, world)
-    fg = FrameGather(plan, W, torch.int32, "cpu")
-    fr = FrameGather(plan, W, torch.float32, "cpu", trailing=(3,))
+    fg = FrameGather(plan, W, torch.int32, "cpu", rank=rank)
+    fr = FrameGather(plan, W, torch.float32, "cpu", trailing=(3,), rank=rank)
     for y, n, ly in plan.rows_of(rank):
         a, r, _ = O.render(sc.c, cam, y, n)
         fg.local[ly:ly + n] = torch.from_numpy(a[y:y + n].view(np.int32))

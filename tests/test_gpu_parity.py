@@ -261,6 +261,15 @@ def test_interleaved_blocks_rebuild_the_frame(torch_cuda, make_scene):
         assert np.array_equal(ga.cpu().numpy().view(np.uint32), full_a)
         assert np.array_equal(gr.cpu().numpy().view(np.uint32), full_r.view(np.uint32))
         assert rays == rays_of(st_full)
+        # the library's own de-interleave copy (what the multi-GPU host runs behind the all-gather), on the
+        # 16-byte path (W % 4 == 0) and, through an odd sub-width, on the per-pixel path
+        for w in (W, W - 3):
+            stacked = torch.stack([p[:, :w].contiguous() for p in parts_a]).reshape(-1, w)
+            frame = torch.full((H, w), -1, dtype=torch.int32, device="cuda")
+            _lib.check(_lib.load().rt_hip_deinterleave(stacked.data_ptr(), frame.data_ptr(), w, H, nph, None),
+                       "rt_hip_deinterleave")
+            torch.cuda.synchronize()
+            assert np.array_equal(frame.cpu().numpy().view(np.uint32), full_a[:, :w])
     ctx.close()
 
 
