@@ -476,7 +476,7 @@ __device__ __forceinline__ void block_copy(float4 *dst, const float4 *src, uint3
  * TILED: the sphere list does not fit one LDS tile; the tile loop contains block barriers, so
  * every thread of the block must call this function (inactive lanes pass active=false).
  */
-template <bool TILED, bool FILTERED, bool ANYHIT, bool STATS>
+template <bool TILED, bool FILTERED, bool ANYHIT, bool STATS, bool BIG>
 __device__ __forceinline__ void intersect_all(const DevScene &S, const float4 *lds_poly,
                                               float4 *lds_sph, bool active, const Ray &r,
                                               uint32_t exc_sph, uint32_t exc_poly, float &out_d,
@@ -494,39 +494,76 @@ __device__ __forceinline__ void intersect_all(const DevScene &S, const float4 *l
             __syncthreads();
         }
         if (active && !(ANYHIT && !STATS && found)) {
-            for (uint32_t j = 0; j < cnt; ++j) {
-                const float4 s = lds_sph[j]; /* same address in all lanes: LDS broadcast */
-                if (FILTERED && (t0 + j) == exc_sph)
-                    continue;
-                tl.sph_test();
-                /* ray.c:185-195 */
+            /* one sphere against this lane's ray: ray.c:185-195 up to the discriminant */
+            auto discriminant = [&](const float4 s, float &B) -> float {
                 const float ex = r.ox - s.x, ey = r.oy - s.y, ez = r.oz - s.z;
-                const float B = 2.0f * ((r.dx * ex + r.dy * ey) + r.dz * ez);
+                B = 2.0f * ((r.dx * ex + r.dy * ey) + r.dz * ez);
                 const float Cq = ((ex * ex + ey * ey) + ez * ez) - s.w;
-                const float det = (B * B) - (4.0f * Cq);
-                if (!(det < 0.0f)) {
-                    tl.sph_hit();
-                    if (FILTERED) {
-                        /* only 0 < w < magnitude can be accepted; w > 0 needs B < 0 */
-                        if (B < 0.0f) {
-                            const float w = sphere_distance(B, det);
-                            if (w < r.mag && w > 0.0f) {
-                                if (!found || w < d) {
-                                    d = w;
-                                    best_k = t0 + j;
-                                    found = true;
-                                    if (ANYHIT && !STATS)
-                                        break;
-                                }
-                            }
-                        }
-                    } else {
+                return (B * B) - (4.0f * Cq);
+            };
+            /* a sphere whose discriminant is not negative: ray.c:209-240 and the caller's filter */
+            auto candidate = [&](uint32_t k, float B, float det) {
+                tl.sph_hit();
+                if (FILTERED) {
+                    /* only 0 < w < magnitude can be accepted; w > 0 needs B < 0 */
+                    if (B < 0.0f) {
                         const float w = sphere_distance(B, det);
-                        if (!found || w < d) {
+                        if (w < r.mag && w > 0.0f && (!found || w < d)) {
                             d = w;
-                            best_k = t0 + j;
+                            best_k = k;
                             found = true;
                         }
+                    }
+                } else {
+                    const float w = sphere_distance(B, det);
+                    if (!found || w < d) {
+                        d = w;
+                        best_k = k;
+                        found = true;
+                    }
+                }
+            };
+            uint32_t j = 0;
+            if (BIG) {
+                /* Scenes with hundreds of spheres: four spheres per trip.  The four LDS reads are
+                 * in flight together and the loop's scalar bookkeeping is shared; with one sphere
+                 * per trip every test waited out its own LDS round trip at 2-3 waves per SIMD (the
+                 * sphere tile leaves room for no more).  Candidates are still taken in list order. */
+                for (; j + 4u <= cnt; j += 4u) {
+                    const float4 s0 = lds_sph[j], s1 = lds_sph[j + 1u], s2 = lds_sph[j + 2u], s3 = lds_sph[j + 3u];
+                    float B0, B1, B2, B3;
+                    float det0 = discriminant(s0, B0), det1 = discriminant(s1, B1);
+                    float det2 = discriminant(s2, B2), det3 = discriminant(s3, B3);
+                    if (FILTERED && exc_sph - (t0 + j) < 4u) { /* the excluded sphere is in this group */
+                        const uint32_t e = exc_sph - (t0 + j);
+                        det0 = e == 0u ? -1.0f : det0; det1 = e == 1u ? -1.0f : det1;
+                        det2 = e == 2u ? -1.0f : det2; det3 = e == 3u ? -1.0f : det3;
+                        if (STATS) { tl.sph_test(); tl.sph_test(); tl.sph_test(); }
+                    } else if (STATS) {
+                        tl.sph_test(); tl.sph_test(); tl.sph_test(); tl.sph_test();
+                    }
+                    if (!(det0 < 0.0f) || !(det1 < 0.0f) || !(det2 < 0.0f) || !(det3 < 0.0f)) {
+                        if (!(det0 < 0.0f)) candidate(t0 + j, B0, det0);
+                        if (!(det1 < 0.0f)) candidate(t0 + j + 1u, B1, det1);
+                        if (!(det2 < 0.0f)) candidate(t0 + j + 2u, B2, det2);
+                        if (!(det3 < 0.0f)) candidate(t0 + j + 3u, B3, det3);
+                        if (ANYHIT && !STATS && found)
+                            break;
+                    }
+                }
+            }
+            if (!(BIG && ANYHIT && !STATS && found)) {
+                for (; j < cnt; ++j) {
+                    const float4 s = lds_sph[j]; /* same address in all lanes: LDS broadcast */
+                    if (FILTERED && (t0 + j) == exc_sph)
+                        continue;
+                    tl.sph_test();
+                    float B;
+                    const float det = discriminant(s, B);
+                    if (!(det < 0.0f)) {
+                        candidate(t0 + j, B, det);
+                        if (ANYHIT && !STATS && found)
+                            break;
                     }
                 }
             }
@@ -784,7 +821,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
         tinypush(sh);
         float sd;
         uint32_t sobj;
-        intersect_all<TILED, true, true, STATS>(S, lds_poly, lds_sph, hit, sh, exc_sph, exc_poly, sd,
+        intersect_all<TILED, true, true, STATS, !TABLDS>(S, lds_poly, lds_sph, hit, sh, exc_sph, exc_poly, sd,
                                                 sobj, tl);
         if (hit && sobj == RT_NONE)
             visible |= 1u << (l & 31u);
@@ -974,7 +1011,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
             cr.dx = back[3 * RT_BLOCK]; cr.dy = back[4 * RT_BLOCK]; cr.dz = back[5 * RT_BLOCK];
             cr.mag = back[6 * RT_BLOCK];
         }
-        intersect_all<TILED, true, false, STATS>(S, lds_poly, lds_sph, want, cr, RT_NONE, RT_NONE, cd, cobj, tl);
+        intersect_all<TILED, true, false, STATS, !TABLDS>(S, lds_poly, lds_sph, want, cr, RT_NONE, RT_NONE, cd, cobj, tl);
         const bool chit = want && (cobj != RT_NONE);
         if (child == 0u) {
             hit_r = chit;
@@ -1171,7 +1208,7 @@ __device__ __forceinline__ void flush_tally(uint64_t *st, Tally<STATS> &tl, bool
 /* k_primary: get_pixel_color + get_ray_color + depth-0 get_shade_color_phong, fused           */
 /* ------------------------------------------------------------------------------------------ */
 template <bool TILED, bool STATS, bool TABLDS>
-__global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_primary(DevScene S, DevCamera C, DevWork Wk,
+__global__ __launch_bounds__(RT_BLOCK, (TABLDS ? 6 : RT_WPE)) void k_primary(DevScene S, DevCamera C, DevWork Wk,
                                                       DevRows R)
 {
     extern __shared__ __attribute__((aligned(16))) float4 lds[];
@@ -1222,7 +1259,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WPE) void k_primary(DevScene S, DevCam
 
             float d;
             uint32_t obj;
-            intersect_all<TILED, false, false, STATS>(S, lds_poly, lds_sph, valid, r, RT_NONE, RT_NONE,
+            intersect_all<TILED, false, false, STATS, !TABLDS>(S, lds_poly, lds_sph, valid, r, RT_NONE, RT_NONE,
                                                       d, obj, tl);
             const bool hit = valid && (obj != RT_NONE);
             float leaf[3] = {kc[KC_BG + 0], kc[KC_BG + 1], kc[KC_BG + 2]}; /* miss: raytrace.c:700-703 */
