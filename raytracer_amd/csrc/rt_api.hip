@@ -97,6 +97,7 @@ struct rt_hip_ctx {
     uint32_t seen_hits[RT_MAX_LEVELS] = {0};
     uint32_t seen_nodes[RT_MAX_LEVELS] = {0};
     bool seen_valid = false;
+    double seen_density = 0.0; /* entries per sample the fullest shard of the last frame needed */
     uint64_t seen_key[3] = {0, 0, 0}; /* frame the counts belong to: they are dropped when it changes */
 };
 
@@ -224,11 +225,31 @@ bool batch_overflowed(const uint32_t *cnt)
 }
 
 /* remember how full the level queues / node ranges of a batch got (grid sizing of the next one) */
-void note_levels(rt_hip_ctx *c, const uint32_t *cnt, uint32_t levels, bool first)
+void note_levels(rt_hip_ctx *c, const uint32_t *cnt, uint32_t levels, bool first, uint64_t samples)
 {
     if (first) {
         memset(c->seen_hits, 0, sizeof c->seen_hits);
         memset(c->seen_nodes, 0, sizeof c->seen_nodes);
+        c->seen_density = 0.0;
+    }
+    /* entries the fullest shard needed per sample of this batch: its node range holds the nodes
+     * of all levels, a queue the hits of one level (the next frame's batches are planned with it) */
+    uint32_t need = 0;
+    for (uint32_t sh = 0; sh < RT_SHARDS; ++sh) {
+        uint32_t nodes = 0;
+        for (uint32_t l = 0; l < levels; ++l) {
+            const uint64_t v = *(const uint64_t *)(cnt + CNT_LEVELS + (l * RT_SHARDS + sh) * RT_LINE_WORDS);
+            nodes += (uint32_t)v;
+            if ((uint32_t)(v >> 32) > need)
+                need = (uint32_t)(v >> 32);
+        }
+        if (nodes > need)
+            need = nodes;
+    }
+    if (samples) {
+        const double density = (double)need * RT_SHARDS / (double)samples;
+        if (density > c->seen_density)
+            c->seen_density = density;
     }
     for (uint32_t l = 0; l < levels && l + 1 < RT_MAX_LEVELS; ++l)
         for (uint32_t sh = 0; sh < RT_SHARDS; ++sh) {
@@ -338,7 +359,8 @@ int drain(rt_hip_ctx *c)
                 c->todo.push_back({b.t0, mid, 0});
             } else {
                 accumulate(c->stats, cnt, c->C.depth + 1);
-                note_levels(c, cnt, c->C.depth + 1, c->stats.batches == 0);
+                note_levels(c, cnt, c->C.depth + 1, c->stats.batches == 0,
+                            (uint64_t)(b.t1 - b.t0) * 8u * c->C.W * c->C.sqrtSpp * c->C.sqrtSpp);
                 c->stats.batches++;
             }
         }
@@ -403,6 +425,11 @@ uint64_t default_batch_samples(const rt_hip_ctx *c)
      * in which more than half the samples queue two hits are rare, and a batch that does outgrow
      * the queues is split and rendered again (drain), so the plan is one sample per entry. */
     uint64_t m = c->cap;
+    /* ... unless the last frame of the same shape showed that this scene needs more than one entry
+     * per sample (mirror-heavy scenes: config 4 queues 1.2 hits per sample): plan for that, with 15 %
+     * to spare, instead of rendering an oversized batch in vain first */
+    if (c->seen_valid && c->seen_density * 1.15 > 1.0)
+        m = (uint64_t)((double)c->cap / (c->seen_density * 1.15));
     if (c->batch_samples && c->batch_samples < m)
         m = c->batch_samples;
     return m ? m : 1;

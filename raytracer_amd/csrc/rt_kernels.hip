@@ -30,6 +30,9 @@
 
 #include <math.h>
 
+#ifndef RT_SPHERES_PER_TRIP
+#define RT_SPHERES_PER_TRIP 8u
+#endif
 #ifndef RT_WPE
 #define RT_WPE 1 /* min waves per SIMD asked of the register allocator (launch_bounds 2nd arg) */
 #endif
@@ -525,28 +528,32 @@ __device__ __forceinline__ void intersect_all(const DevScene &S, const float4 *l
             };
             uint32_t j = 0;
             if (BIG) {
-                /* Scenes with hundreds of spheres: four spheres per trip.  The four LDS reads are
+                /* Scenes with hundreds of spheres: RT_SPHERES_PER_TRIP spheres per trip.  The LDS reads are
                  * in flight together and the loop's scalar bookkeeping is shared; with one sphere
                  * per trip every test waited out its own LDS round trip at 2-3 waves per SIMD (the
                  * sphere tile leaves room for no more).  Candidates are still taken in list order. */
-                for (; j + 4u <= cnt; j += 4u) {
-                    const float4 s0 = lds_sph[j], s1 = lds_sph[j + 1u], s2 = lds_sph[j + 2u], s3 = lds_sph[j + 3u];
-                    float B0, B1, B2, B3;
-                    float det0 = discriminant(s0, B0), det1 = discriminant(s1, B1);
-                    float det2 = discriminant(s2, B2), det3 = discriminant(s3, B3);
-                    if (FILTERED && exc_sph - (t0 + j) < 4u) { /* the excluded sphere is in this group */
-                        const uint32_t e = exc_sph - (t0 + j);
-                        det0 = e == 0u ? -1.0f : det0; det1 = e == 1u ? -1.0f : det1;
-                        det2 = e == 2u ? -1.0f : det2; det3 = e == 3u ? -1.0f : det3;
-                        if (STATS) { tl.sph_test(); tl.sph_test(); tl.sph_test(); }
-                    } else if (STATS) {
-                        tl.sph_test(); tl.sph_test(); tl.sph_test(); tl.sph_test();
+                constexpr uint32_t U = RT_SPHERES_PER_TRIP;
+                for (; j + U <= cnt; j += U) {
+                    float Bq[U], detq[U];
+                    float4 sq[U];
+#pragma unroll
+                    for (uint32_t u = 0; u < U; ++u)
+                        sq[u] = lds_sph[j + u];
+                    bool any = false;
+#pragma unroll
+                    for (uint32_t u = 0; u < U; ++u) {
+                        detq[u] = discriminant(sq[u], Bq[u]);
+                        if (FILTERED && (t0 + j + u) == exc_sph)
+                            detq[u] = -1.0f; /* the excluded sphere: never a candidate, never counted */
+                        else
+                            tl.sph_test();
+                        any = any || !(detq[u] < 0.0f);
                     }
-                    if (!(det0 < 0.0f) || !(det1 < 0.0f) || !(det2 < 0.0f) || !(det3 < 0.0f)) {
-                        if (!(det0 < 0.0f)) candidate(t0 + j, B0, det0);
-                        if (!(det1 < 0.0f)) candidate(t0 + j + 1u, B1, det1);
-                        if (!(det2 < 0.0f)) candidate(t0 + j + 2u, B2, det2);
-                        if (!(det3 < 0.0f)) candidate(t0 + j + 3u, B3, det3);
+                    if (any) {
+#pragma unroll
+                        for (uint32_t u = 0; u < U; ++u)
+                            if (!(detq[u] < 0.0f))
+                                candidate(t0 + j + u, Bq[u], detq[u]);
                         if (ANYHIT && !STATS && found)
                             break;
                     }
