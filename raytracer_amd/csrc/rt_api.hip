@@ -71,7 +71,9 @@ struct rt_hip_ctx {
     uint32_t *roots = nullptr; /* [spp^2][pixels of a batch] */
     size_t roots_cap = 0;
     uint32_t *d_counters = nullptr; /* [kMaxBatches][RT_COUNTER_WORDS] */
-    uint32_t *h_counters = nullptr; /* pinned mirror */
+    uint32_t *h_counters = nullptr; /* pinned, device-mapped mirror (written by k_publish) */
+    uint32_t *h_counters_dev = nullptr; /* its device address */
+    bool counters_dirty = false;    /* a render was abandoned midway: blocks may not be zero */
     /* pending render */
     bool pending = false;
     bool pending_stats = false;
@@ -184,7 +186,7 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
     Wk.roots = c->roots;
     Wk.counters = c->d_counters + (size_t)b.slot * c->cwords;
     hipStream_t st = c->stream;
-    HIP_TRY(hipMemsetAsync(Wk.counters, 0, c->cwords * sizeof(uint32_t), st));
+    /* the counter block is zero: k_publish at the end of its last use left it so */
     const bool timed = c->timing && !stats;
     if (timed) {
         hipEvent_t e0, e1;
@@ -203,6 +205,7 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
     for (uint32_t d = depth; d-- > 1;) /* nodes exist on levels 0..depth-1; level 0 folds in resolve */
         rt_launch_fold(Wk, d, c->seen_valid ? (c->seen_nodes[d] ? c->seen_nodes[d] : 1u) : 0u, st);
     rt_launch_resolve(c->C, Wk, R, c->d_argb, c->d_rad, st);
+    rt_launch_publish(Wk.counters, c->h_counters_dev + (size_t)b.slot * c->cwords, (uint32_t)c->cwords, st);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -321,10 +324,7 @@ int enqueue_round(rt_hip_ctx *c)
             return rc;
         c->batches.push_back(b);
     }
-    if (!c->batches.empty()) {
-        HIP_TRY(hipMemcpyAsync(c->h_counters, c->d_counters,
-                               c->batches.size() * c->cwords * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                               c->stream));
+    if (!c->batches.empty()) { /* (each batch ended by publishing its counters to h_counters) */
         if (!c->round_done)
             HIP_TRY(hipEventCreateWithFlags(&c->round_done, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(c->round_done, c->stream));
@@ -510,7 +510,11 @@ int rt_hip_ctx_create(rt_hip_ctx **out, int device, uint64_t max_queue_rays)
         e = hipMalloc((void **)&c->d_counters, (size_t)kMaxBatches * RT_COUNTER_WORDS * sizeof(uint32_t));
     if (e == hipSuccess)
         e = hipHostMalloc((void **)&c->h_counters, (size_t)kMaxBatches * RT_COUNTER_WORDS * sizeof(uint32_t),
-                          hipHostMallocDefault);
+                          hipHostMallocMapped);
+    if (e == hipSuccess)
+        e = hipHostGetDevicePointer((void **)&c->h_counters_dev, c->h_counters, 0);
+    if (e == hipSuccess)
+        e = hipMemset(c->d_counters, 0, (size_t)kMaxBatches * RT_COUNTER_WORDS * sizeof(uint32_t));
     if (e != hipSuccess) {
         set_err("allocating %zu bytes of queue memory failed: %s", arr * 9 + arr / 2, hipGetErrorString(e));
         rt_hip_ctx_destroy(c);
@@ -693,6 +697,11 @@ static int submit(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb, float *
         if (rc)
             return rc;
     }
+    if (c->counters_dirty) { /* a render died between its first kernel and its k_publish */
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemset(c->d_counters, 0, (size_t)kMaxBatches * RT_COUNTER_WORDS * sizeof(uint32_t)));
+        c->counters_dirty = false;
+    }
     c->cam = *cam;
     fold_camera(c->C, *cam);
     {
@@ -726,7 +735,10 @@ static int submit(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb, float *
         c->todo.push_back({t - n, t, 0});
         t -= n;
     }
-    return enqueue_round(c);
+    rc = enqueue_round(c);
+    if (rc)
+        c->counters_dirty = true;
+    return rc;
 }
 
 int rt_hip_render_rows(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb, float *d_rad,
@@ -777,6 +789,8 @@ int rt_hip_finish(rt_hip_ctx *c, rt_hip_stats *stats)
         ev.swap(c->ev);
         c->timing = false;
         rc = drain(c);
+        if (rc && rc != RT_E_OVERFLOW)
+            c->counters_dirty = true;
         c->timing = was_timing;
         c->pending = false;
         for (size_t i = 0; i + 1 < ev.size(); i += 2) {

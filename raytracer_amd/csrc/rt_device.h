@@ -141,6 +141,7 @@ enum {
 };
 #define RT_COUNTER_WORDS_FOR(levels) (CNT_LEVELS + (levels) * RT_SHARDS * RT_LINE_WORDS)
 #define RT_COUNTER_WORDS RT_COUNTER_WORDS_FOR(RT_MAX_LEVELS)
+static_assert(CNT_LEVELS % 4 == 0 && (RT_SHARDS * RT_LINE_WORDS) % 4 == 0, "counter blocks are copied 16 bytes at a time");
 
 /* uint64 statistic slots of a shard */
 enum {
@@ -167,6 +168,7 @@ void rt_launch_fold(const DevWork &Wk, uint32_t level, uint32_t expect, hipStrea
 void rt_launch_resolve(const DevCamera &C, const DevWork &Wk, const DevRows &R, uint32_t *d_argb,
                        float *d_radiance, hipStream_t stream);
 size_t rt_scene_lds_bytes(const DevScene &S);
+void rt_launch_publish(uint32_t *counters, uint32_t *mirror, uint32_t words, hipStream_t stream);
 void rt_launch_deinterleave(const uint32_t *gathered, uint32_t *frame, uint32_t width, uint32_t height,
                             uint32_t nphases, hipStream_t stream);
 void rt_launch_selftest_arith(const float *a, const float *b, const float *c, uint32_t n, float *out,

@@ -1509,6 +1509,17 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DevCamera C, DevWork Wk, D
     }
 }
 
+/* k_publish: end of a batch - its counter block goes to the host's pinned mirror (mapped memory:
+ * plain stores over the link) and is zeroed for its next use.  One small kernel in place of a
+ * device-to-host copy plus a memset command, each of which cost ~10 us of queue latency per frame. */
+__global__ __launch_bounds__(RT_BLOCK) void k_publish(uint4 *counters, uint4 *mirror, uint32_t n16)
+{
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n16; i += gridDim.x * RT_BLOCK) {
+        mirror[i] = counters[i];
+        counters[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
 /* rt_hip_deinterleave: frame row y = block b*8 + line; b = k*nphases + r lives at gathered row
  * (r*blocks_per_rank + k)*8 + line.  One thread per 16 bytes when the width allows, else per pixel. */
 template <typename T>
@@ -1670,4 +1681,10 @@ void rt_launch_deinterleave(const uint32_t *gathered, uint32_t *frame, uint32_t 
     else
         k_deinterleave<uint32_t><<<(uint32_t)grid, RT_BLOCK, 0, stream>>>(gathered, frame, row_words, height,
                                                                            nphases, blocks_per_rank);
+}
+
+void rt_launch_publish(uint32_t *counters, uint32_t *mirror, uint32_t words, hipStream_t stream)
+{
+    const uint32_t n16 = words / 4u; /* the block is a whole number of 16-byte pieces (rt_device.h) */
+    k_publish<<<(n16 + RT_BLOCK - 1) / RT_BLOCK, RT_BLOCK, 0, stream>>>((uint4 *)counters, (uint4 *)mirror, n16);
 }
