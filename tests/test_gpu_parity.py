@@ -163,8 +163,10 @@ def test_c2_full_frame_parity_counts_and_hash(torch_cuda, golden, make_scene):
     argb, rad, st = render_dev(torch_cuda, ctx, cam)
     a_o, r_o, c_o = O.render(sc.c, cam, nthreads=16)
     exact = assert_parity(argb, rad, a_o, r_o, "C2")
-    assert exact > 0.8
-    assert (argb != a_o).mean() < 1e-4            # 8-bit image: all but a handful of pixels identical
+    assert exact > 0.99                           # measured 0.99942: the rest is 1-5 ulp off (sum order)
+    assert (argb != a_o).sum() <= 16              # 8-bit image: measured 0 differing pixels of 2 073 600
+    if (argb == a_o).all():                       # then the P6 file is the reference's own, hash and all
+        assert ppm_md5(argb, 1920, 1080) == fr["md5"]
     # counts: deterministic functions of scene + camera; a flipped silhouette sample moves them by a few
     ref_rays = fr["counts"]["ray_create"] + fr["counts"]["ray_tinypush"] - (fr["counts"]["ray_create"] - 1920 * 1080 * 16)
     assert abs(rays_of(st) - ref_rays) <= 64
