@@ -102,8 +102,8 @@ def cpu_baseline(W, H, sqrt_spp, depth, budget_rows):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--sqrt-spp", type=int, default=4)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--inflight", type=int, default=2,
