@@ -63,6 +63,7 @@ struct rt_hip_ctx {
     bool have_scene = false;
     DevScene S{};
     void *scene_blob = nullptr;
+    std::vector<char> scene_host; /* what scene_blob holds */
     /* work buffers */
     void *work_blob = nullptr;
     DevWork W{};
@@ -647,13 +648,20 @@ int rt_hip_scene_upload(rt_hip_ctx *c, const rt_scene *sc)
     for (const Seg &s : segs)
         if (s.bytes)
             memcpy(host.data() + s.off, s.src, s.bytes);
-    if (c->scene_blob) {
-        HIP_TRY(hipFree(c->scene_blob));
-        c->scene_blob = nullptr;
-        c->have_scene = false;
+    /* the blocking host path uploads the scene on every call (the caller may have edited it):
+     * an unchanged scene - the common case, frame after frame - keeps the device copy */
+    const bool same = c->have_scene && c->scene_blob && c->scene_host == host && c->S.nSph == nSph &&
+                      c->S.nPoly == nPoly && c->S.nObj == nObj && c->S.nLights == nL;
+    if (!same) {
+        if (c->scene_blob) {
+            HIP_TRY(hipFree(c->scene_blob));
+            c->scene_blob = nullptr;
+            c->have_scene = false;
+        }
+        HIP_TRY(hipMalloc(&c->scene_blob, total));
+        HIP_TRY(hipMemcpy(c->scene_blob, host.data(), total, hipMemcpyHostToDevice));
+        c->scene_host.swap(host);
     }
-    HIP_TRY(hipMalloc(&c->scene_blob, total));
-    HIP_TRY(hipMemcpy(c->scene_blob, host.data(), total, hipMemcpyHostToDevice));
     char *b = (char *)c->scene_blob;
     DevScene &S = c->S;
     S.sph = (const float4 *)(b + segs[0].off);
@@ -680,7 +688,8 @@ int rt_hip_scene_upload(rt_hip_ctx *c, const rt_scene *sc)
         return RT_E_INVALID;
     }
     c->have_scene = true;
-    c->seen_valid = false;
+    if (!same)
+        c->seen_valid = false;
     return 0;
 }
 
@@ -833,6 +842,9 @@ int rt_hip_render_stats(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb, f
 
 static std::mutex g_mu;
 static rt_hip_ctx *g_ctx = nullptr; /* cached context of the blocking host path */
+static uint32_t *g_argb = nullptr;  /* ... and its device frame buffers (grow-only) */
+static float *g_rad = nullptr;
+static size_t g_argb_px = 0, g_rad_px = 0;
 
 int rt_hip_render(const rt_scene *scene, const rt_camera *cam, rt_framebuffer *fb)
 {
@@ -865,17 +877,24 @@ int rt_hip_render(const rt_scene *scene, const rt_camera *cam, rt_framebuffer *f
     if (rc)
         return rc;
     const size_t npix = (size_t)fb->width * fb->height;
-    uint32_t *d_argb = nullptr;
-    float *d_rad = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_argb, npix * sizeof(uint32_t)));
-    if (fb->radiance) {
-        hipError_t e = hipMalloc((void **)&d_rad, npix * 3 * sizeof(float));
-        if (e != hipSuccess) {
-            (void)hipFree(d_argb);
-            set_err("hipMalloc radiance: %s", hipGetErrorString(e));
-            return -(int)e;
-        }
+    if (npix > g_argb_px) {
+        if (g_argb)
+            (void)hipFree(g_argb);
+        g_argb = nullptr;
+        g_argb_px = 0;
+        HIP_TRY(hipMalloc((void **)&g_argb, npix * sizeof(uint32_t)));
+        g_argb_px = npix;
     }
+    if (fb->radiance && npix > g_rad_px) {
+        if (g_rad)
+            (void)hipFree(g_rad);
+        g_rad = nullptr;
+        g_rad_px = 0;
+        HIP_TRY(hipMalloc((void **)&g_rad, npix * 3 * sizeof(float)));
+        g_rad_px = npix;
+    }
+    uint32_t *d_argb = g_argb;
+    float *d_rad = fb->radiance ? g_rad : nullptr;
     rc = rt_hip_render_rows(g_ctx, cam, d_argb, d_rad, fb->row0, fb->nrows, nullptr);
     if (!rc)
         rc = rt_hip_finish(g_ctx, nullptr);
@@ -890,9 +909,6 @@ int rt_hip_render(const rt_scene *scene, const rt_camera *cam, rt_framebuffer *f
             rc = -(int)e;
         }
     }
-    (void)hipFree(d_argb);
-    if (d_rad)
-        (void)hipFree(d_rad);
     return rc;
 }
 
