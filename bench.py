@@ -73,6 +73,21 @@ def measured_traffic(W, H, sqrt_spp, depth):
     return t["k_primary"]["bytes_per_launch"]
 
 
+def cpu_all_cores(O, sc, W, H, sqrt_spp, depth):
+    """the oracle port with its row-parallel OpenMP loop on the host cores this job
+    may use (OMP_NUM_THREADS on the GPU box, else the CPU count, at most 16), two full frames."""
+    cores = max(1, min(16, int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)))
+    cam = O.prepare_camera(sc.c, W, H, sqrt_spp, depth)
+    t0 = time.perf_counter()
+    rays = 0
+    for _ in range(2):
+        _, _, cnt = O.render(sc.c, cam, 0, H, nthreads=cores)
+        rays += cnt["primary_rays"] + cnt["shadow_rays"] + cnt["reflection_rays"] + cnt["transmission_rays"]
+    dt = time.perf_counter() - t0
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"2 full {W}x{H} frames, oracle/rt_oracle.c -O2 -fopenmp, {dt:.2f} s"}
+
+
 def cpu_baseline(W, H, sqrt_spp, depth, budget_rows):
     """Reference (oracle/_ref, when it travelled) or the oracle port on ONE host core, on a row
     slab of the same frame.  Returns the JSON object."""
@@ -92,7 +107,8 @@ def cpu_baseline(W, H, sqrt_spp, depth, budget_rows):
             rays += cnt["ray_create"] + (cnt["ray_tinypush"] - (cnt["ray_create"] - W * H * sqrt_spp * sqrt_spp))
         return {"value": rays / total / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "reference",
                 "sample": f"{frames} full {W}x{H} frames, sqrtSpp {sqrt_spp}, depth {depth}, gcc -O2 build of the "
-                          f"untouched reference, single-threaded like the reference, {total:.2f} s"}
+                          f"untouched reference, single-threaded like the reference, {total:.2f} s",
+                "all_cores": cpu_all_cores(O, sc, W, H, sqrt_spp, depth)}
     cam = O.prepare_camera(sc.c, W, H, sqrt_spp, depth)
     t0 = time.perf_counter()
     _, _, cnt = O.render(sc.c, cam, row0, budget_rows, nthreads=1)
