@@ -58,6 +58,11 @@ def oracle():
     return _oracle
 
 
+def set_rounded_pow(on):
+    """diagnostic: correctly rounded specular power instead of libm's powf (rt_oracle.c)"""
+    oracle().rt_oracle_set_rounded_pow(int(bool(on)))
+
+
 def prepare_camera(scene_t, W, H, sqrt_spp, depth, fov_y=45.0, aspect=None, near_z=1.0):
     cam = A.rt_camera()
     if aspect is None:

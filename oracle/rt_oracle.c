@@ -45,6 +45,28 @@ typedef struct {
     rt_oracle_counts *cnt;
 } ctx_t;
 
+/* DIAGNOSTIC switch (off by default: the oracle then calls libm's powf, like the reference,
+ * raytrace.c:371).  glibc 2.35's powf is faithfully but not correctly rounded: for ~0.07 % of
+ * arguments it returns the float on the other side of the exact power.  With the switch on, the
+ * specular power is the correctly rounded one (exact product chain in double for an integral
+ * exponent), which is what the HIP kernels compute; tests use it to show that libm's rounding is
+ * the ONLY difference left between the kernels and the reference. */
+static int g_rounded_pow;
+void rt_oracle_set_rounded_pow(int on) { g_rounded_pow = on; }
+static float rounded_pow(float s, float ke)
+{
+    const int e = (int)ke;
+    if ((float)e != ke || e < 0 || e > 4096)
+        return powf(s, ke);
+    double r = 1.0, b = (double)s;
+    for (int k = e; k; k >>= 1) {
+        if (k & 1)
+            r *= b;
+        b *= b;
+    }
+    return (float)r;
+}
+
 /* ---- vector4.c ------------------------------------------------------------------------ */
 
 static v3 v3_from(const rt_vec4 *p) { v3 r = {p->x, p->y, p->z}; return r; }
@@ -285,7 +307,7 @@ static rt_color shade(const ctx_t *c, const rt_object3d *obj, const ray_t *eye, 
         float s = dot(R, V);
         if (s < 0.0f)
             s = 0.0f;
-        s = powf(s, m->phong_ke);
+        s = g_rounded_pow ? rounded_pow(s, m->phong_ke) : powf(s, m->phong_ke);
         spec.r += L->color.r * s;
         spec.g += L->color.g * s;
         spec.b += L->color.b * s;

@@ -1274,10 +1274,24 @@ __global__ __launch_bounds__(RT_BLOCK, (TABLDS ? 6 : RT_WPE)) void k_primary(Dev
             bool sr, st_;
             const float px = r.ox + r.dx * d, py = r.oy + r.dy * d, pz = r.oz + r.dz * d;
             const PrimaryEye eye_src{cam, fu0, fv0, i, j};
-            const bool deferred = shade_and_spawn<TILED, STATS, TABLDS>(S, C, Wk, lds_poly, lds_sph, lds_vis, lds_park, kc, tab, hit,
-                                                                eye_src, px, py, pz, obj, 0u, RT_LINK_NONE << 3, shard,
-                                                                node_base, Wk.capS, leaf, node, sr, st_, tl, pc);
+            bool deferred = shade_and_spawn<TILED, STATS, TABLDS>(S, C, Wk, lds_poly, lds_sph, lds_vis, lds_park, kc, tab, hit,
+                                                          eye_src, px, py, pz, obj, 0u, RT_LINK_NONE << 3, shard,
+                                                          node_base, Wk.capS, leaf, node, sr, st_, tl, pc);
             sc.add(hit, sr, st_);
+            /* The reference adds a pixel's samples in order (raytrace.c:774) and float addition does
+             * not commute: a finished sample that FOLLOWS a root of its pixel must be added after
+             * that root, so it becomes a childless root itself (silhouette pixels only: rare). */
+            if (valid && !deferred && nroots != 0u) {
+                uint32_t local, no_r, no_t;
+                wave_reserve(level_line(Wk.counters, 0u, shard), false, false, Wk.capS, Wk.capS,
+                             &Wk.counters[CNT_OVERFLOW + 0u], local, no_r, no_t);
+                if (local != RT_NONE) {
+                    node = node_base + local;
+                    Wk.nodeA()[node] = make_float4(leaf[0], leaf[1], leaf[2], 0.0f);
+                    Wk.nodeK()[node] = make_float2(0.0f, __uint_as_float(RT_LINK_NONE << 3));
+                    deferred = true;
+                }
+            }
             if (deferred) {
                 Wk.roots[(size_t)nroots * pix_stride + pix] = node; /* resolved by k_resolve */
                 ++nroots;

@@ -5,7 +5,9 @@ Tolerances (north_star): 8-bit RGB within +-1 LSB on >= 99.9 % of pixels; per-pi
 relative error <= 1e-4 (checked on >= 99.9 % of pixels - a silhouette sample that flips between a
 hit and a miss changes its pixel by far more than any tolerance, on the CPU across compilers too:
 SURVEY.md appendix C.1).  In practice the kernels reproduce the reference's float operations one by
-one and the observed median error is 0.
+one, in its order: every pixel is bit-identical to the oracle once libm's powf rounding is taken
+out (test_radiance_is_bit_identical_but_for_libm_powf), and 9 of 2 073 600 pixels are 1-2 ulp off
+with it in.
 """
 import ctypes as C
 
@@ -73,6 +75,29 @@ def test_against_oracle(make_scene, name, W, H, s, d):
         assert np.allclose(rad, r_o, rtol=1e-4, atol=1e-7)
     else:
         assert_parity(argb, rad, a_o, r_o, f"{name} {W}x{H}")
+
+
+@pytest.mark.parametrize("name,W,H,s,d", [
+    ("builtin", 640, 480, 1, 4), ("builtin", 333, 217, 3, 5), ("builtin", 1920, 1080, 4, 8),
+    ("syn64", 160, 120, 2, 4), ("syn300", 128, 96, 2, 6), ("syn3000", 64, 48, 2, 3),
+])
+def test_radiance_is_bit_identical_but_for_libm_powf(make_scene, name, W, H, s, d):
+    """The kernels perform the reference's float operations one by one, in its order (the samples of
+    a pixel included: raytrace.c:774).  The one thing they do not imitate is the LAST-BIT behaviour of
+    glibc's powf (raytrace.c:371), which is faithfully, not correctly, rounded (~0.07 % of arguments
+    land on the other float); the kernels return the correctly rounded power.  With the oracle's
+    diagnostic switch for a correctly rounded powf, EVERY pixel's radiance is bit-identical."""
+    sc = make_scene(name)
+    cam = rt.prepare_camera(sc, W, H, s, d)
+    argb, rad = rt.render(sc, cam)
+    O.set_rounded_pow(True)
+    try:
+        a_o, r_o, _ = O.render(sc.c, cam, nthreads=16)
+    finally:
+        O.set_rounded_pow(False)
+    differ = (rad.view(np.uint32) != r_o.view(np.uint32)).any(-1)
+    assert differ.sum() == 0, f"{differ.sum()} pixels differ, first at {np.argwhere(differ)[:4].tolist()}"
+    assert np.array_equal(argb, a_o)
 
 
 def test_raytrace_drop_in_entry_matches_reference_hash(golden):
@@ -163,24 +188,23 @@ def test_c2_full_frame_parity_counts_and_hash(torch_cuda, golden, make_scene):
     argb, rad, st = render_dev(torch_cuda, ctx, cam)
     a_o, r_o, c_o = O.render(sc.c, cam, nthreads=16)
     exact = assert_parity(argb, rad, a_o, r_o, "C2")
-    assert exact > 0.99                           # measured 0.99942: the rest is 1-5 ulp off (sum order)
-    assert (argb != a_o).sum() <= 16              # 8-bit image: measured 0 differing pixels of 2 073 600
-    if (argb == a_o).all():                       # then the P6 file is the reference's own, hash and all
-        assert ppm_md5(argb, 1920, 1080) == fr["md5"]
-    # counts: deterministic functions of scene + camera; a flipped silhouette sample moves them by a few
+    assert exact > 0.9999                         # measured: 9 pixels of 2 073 600 are 1-2 ulp off (libm powf)
+    assert (argb != a_o).sum() == 0               # 8-bit image: identical
+    assert ppm_md5(argb, 1920, 1080) == fr["md5"]  # so the P6 file is the reference's own, hash and all
+    # counts: deterministic functions of scene + camera, equal to the reference's --wrap counters
     ref_rays = fr["counts"]["ray_create"] + fr["counts"]["ray_tinypush"] - (fr["counts"]["ray_create"] - 1920 * 1080 * 16)
-    assert abs(rays_of(st) - ref_rays) <= 64
+    assert rays_of(st) == ref_rays
     assert st.primary_rays == 1920 * 1080 * 16
-    assert abs(st.shadow_rays - c_o["shadow_rays"]) <= 64
-    assert abs(st.reflection_rays - c_o["reflection_rays"]) <= 64
-    assert abs(st.transmission_rays - c_o["transmission_rays"]) <= 64
+    assert st.shadow_rays == c_o["shadow_rays"]
+    assert st.reflection_rays == c_o["reflection_rays"]
+    assert st.transmission_rays == c_o["transmission_rays"]
     # instrumented kernels: algorithmic test counts equal the reference's wrap counters
     argb2, rad2, st2 = render_dev(torch_cuda, ctx, cam, stats=True)
     assert np.array_equal(argb2, argb) and np.array_equal(rad2.view(np.uint32), rad.view(np.uint32))
-    assert abs(st2.sphere_tests - fr["counts"]["sphere_tests"]) <= 256
-    assert abs(st2.sphere_hits - fr["counts"]["sphere_hits"]) <= 256
-    assert abs(st2.polygon_tests - fr["counts"]["polygon_tests"]) <= 256
-    assert abs(st2.polygon_hits - fr["counts"]["polygon_hits"]) <= 256
+    assert st2.sphere_tests == fr["counts"]["sphere_tests"]
+    assert st2.sphere_hits == fr["counts"]["sphere_hits"]
+    assert st2.polygon_tests == fr["counts"]["polygon_tests"]
+    assert st2.polygon_hits == fr["counts"]["polygon_hits"]
     # k_primary's share: primary rays, its shadow rays (own sphere excluded), and the level-1 rays, which
     # the spawning lane traces itself (2 spheres in the builtin scene)
     assert st2.k0_sphere_tests == (2 * st.primary_rays + st2.k0_shadow_rays * 2 - st2.k0_nodes_sphere
