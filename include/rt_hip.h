@@ -170,6 +170,16 @@ void raytrace(unsigned int *buffer, rt_scene_t *scene,
  * Returns 0 or a negative hipError_t / RT_E_* code. */
 int rt_hip_render(const rt_scene *scene, const rt_camera *camera, rt_framebuffer *fb);
 
+/* The same blocking, host-pointer render spread over several GPUs of THIS process: device
+ * devices[r] renders the 8-row blocks b with b % ndevices == r (rt_hip_render_interleaved) and its
+ * blocks are copied straight into the caller's frame - the host frame is the gather point, so no
+ * collective is involved (the reference's Cell host collects its workers' pixels the same way,
+ * ppu/ppu_raytrace.c:312-338).  Whole frames only (row0 = 0, nrows = height).  A device may be
+ * listed more than once.  raytrace() takes this path when the environment names more than one
+ * device: RT_HIP_DEVICES=all or RT_HIP_DEVICES=0,1,2,3.  Pixels are identical to rt_hip_render's. */
+int rt_hip_render_devices(const rt_scene *scene, const rt_camera *camera, rt_framebuffer *fb,
+                          const int *devices, uint32_t ndevices);
+
 /* prepare_scene -- raytrace.c:72-85: fills the view-plane fields of *cam from the
  * projection parameters (double-precision tan, stored to float), copies eye/U/V/N. */
 void rt_camera_prepare(rt_camera *cam, const rt_scene_t *scene,
@@ -185,7 +195,7 @@ typedef struct rt_hip_ctx rt_hip_ctx;
 #define RT_E_NOSCENE   (-10003)   /* render before rt_hip_scene_upload              */
 
 /* Create a render context on HIP device `device` (-1 = current).  max_queue_rays = capacity
- * of each per-level ray queue and of the node pool (0 = default 32 Mi entries). */
+ * of each per-level ray queue and of the node pool (0 = RT_HIP_QUEUE_CAP from the environment, else 64 Mi entries). */
 int  rt_hip_ctx_create(rt_hip_ctx **out, int device, uint64_t max_queue_rays);
 void rt_hip_ctx_destroy(rt_hip_ctx *ctx);
 

@@ -16,6 +16,7 @@ EXPORTS = [
     "rt_hip_ctx_set_timing", "rt_hip_ctx_set_batch_samples", "rt_hip_last_error", "rt_hip_version",
     "rt_poly_plane", "rt_scene_builtin", "rt_parse_scene", "rt_scene_free", "rt_scene_synthetic",
     "rt_write_image", "write_image", "rt_hip_selftest_arith", "rt_load_scene", "rt_hip_deinterleave",
+    "rt_hip_render_devices",
 ]
 
 _lib = None
@@ -40,6 +41,8 @@ def load():
     lib.raytrace.restype = None
     lib.rt_hip_render.argtypes = [P(A.rt_scene), P(A.rt_camera), P(A.rt_framebuffer)]
     lib.rt_hip_render.restype = i32
+    lib.rt_hip_render_devices.argtypes = [P(A.rt_scene), P(A.rt_camera), P(A.rt_framebuffer), P(C.c_int), u32]
+    lib.rt_hip_render_devices.restype = i32
     lib.rt_camera_prepare.argtypes = [P(A.rt_camera), P(A.rt_scene_t), C.c_uint, C.c_uint, C.c_uint, f32, f32, f32, C.c_uint]
     lib.rt_camera_prepare.restype = None
     lib.rt_hip_ctx_create.argtypes = [P(vp), i32, u64]

@@ -95,8 +95,9 @@ def raytrace(buffer, scene, fovY, aspectRatio, nearZ, farZ, width, height, sampl
     return buffer
 
 
-def render(scene, cam, row0=0, nrows=None, want_radiance=True):
-    """rt_hip_render on host arrays: returns (argb[H,W] uint32, radiance[H,W,3] float32 or None)."""
+def render(scene, cam, row0=0, nrows=None, want_radiance=True, devices=None):
+    """rt_hip_render (or, with a device list, rt_hip_render_devices) on host arrays: returns
+    (argb[H,W] uint32, radiance[H,W,3] float32 or None)."""
     W, H = cam.frameBufferWidth, cam.frameBufferHeight
     if nrows is None:
         nrows = H - row0
@@ -107,6 +108,11 @@ def render(scene, cam, row0=0, nrows=None, want_radiance=True):
     fb.radiance = rad.ctypes.data_as(C.POINTER(C.c_float)) if want_radiance else None
     fb.width, fb.height, fb.row0, fb.nrows = W, H, row0, nrows
     view = scene.view()
+    if devices is not None:  # rt_hip_render_devices: whole frames over several GPUs of this process
+        devs = (C.c_int * len(devices))(*devices)
+        check(load().rt_hip_render_devices(C.byref(view), C.byref(cam), C.byref(fb), devs, len(devices)),
+              "rt_hip_render_devices")
+        return argb, rad
     check(load().rt_hip_render(C.byref(view), C.byref(cam), C.byref(fb)), "rt_hip_render")
     return argb, rad
 

@@ -912,6 +912,180 @@ int rt_hip_render(const rt_scene *scene, const rt_camera *cam, rt_framebuffer *f
     return rc;
 }
 
+/* ---- the host-pointer path on several GPUs of this process -------------------------------- */
+
+namespace {
+struct DevSlot { /* one per entry of the caller's device list (the same device may appear twice) */
+    int device = -1;
+    rt_hip_ctx *ctx = nullptr;
+    hipStream_t stream = nullptr;
+    uint32_t *d_argb = nullptr;
+    float *d_rad = nullptr;
+    size_t argb_px = 0, rad_px = 0;
+};
+std::vector<DevSlot> g_slots;
+
+void slot_release(DevSlot &s)
+{
+    if (s.device >= 0)
+        (void)hipSetDevice(s.device);
+    if (s.ctx) rt_hip_ctx_destroy(s.ctx);
+    if (s.d_argb) (void)hipFree(s.d_argb);
+    if (s.d_rad) (void)hipFree(s.d_rad);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+    s = DevSlot();
+}
+
+/* rank r's compact buffer -> its 8-row blocks of the host frame: one strided copy for the whole
+ * blocks, one more for a last block cut short by the frame's end */
+int copy_blocks_back(const DevSlot &s, void *host, const void *dev, size_t px_bytes, uint32_t W, uint32_t H,
+                     uint32_t r, uint32_t n)
+{
+    const uint32_t nblocks = (H + 7u) / 8u;
+    if (r >= nblocks)
+        return 0;
+    const uint32_t mine = (nblocks - r + n - 1u) / n;
+    const size_t block_bytes = (size_t)8u * W * px_bytes;
+    const uint32_t last_b = r + (mine - 1u) * n; /* my last block in the frame */
+    const uint32_t last_rows = (H - last_b * 8u) < 8u ? (H - last_b * 8u) : 8u;
+    const uint32_t whole = last_rows == 8u ? mine : mine - 1u;
+    char *dst = (char *)host + (size_t)r * block_bytes;
+    if (whole)
+        HIP_TRY(hipMemcpy2DAsync(dst, (size_t)n * block_bytes, dev, block_bytes, block_bytes, whole,
+                                 hipMemcpyDeviceToHost, s.stream));
+    if (whole != mine)
+        HIP_TRY(hipMemcpyAsync((char *)host + (size_t)last_b * block_bytes,
+                               (const char *)dev + (size_t)(mine - 1u) * block_bytes,
+                               (size_t)last_rows * W * px_bytes, hipMemcpyDeviceToHost, s.stream));
+    return 0;
+}
+} // namespace
+
+int rt_hip_render_devices(const rt_scene *scene, const rt_camera *cam, rt_framebuffer *fb, const int *devices,
+                          uint32_t ndevices)
+{
+    if (!scene || !cam || !fb || !fb->argb || !devices || ndevices == 0 || ndevices > 64) {
+        set_err("null argument or a device list of %u entries (1..64)", ndevices);
+        return RT_E_INVALID;
+    }
+    if (fb->width != cam->frameBufferWidth || fb->height != cam->frameBufferHeight || fb->row0 != 0 ||
+        fb->nrows != fb->height) {
+        set_err("rt_hip_render_devices renders whole frames: buffer %ux%u rows [%u,+%u), camera %ux%u", fb->width,
+                fb->height, fb->row0, fb->nrows, cam->frameBufferWidth, cam->frameBufferHeight);
+        return RT_E_INVALID;
+    }
+    int have = 0;
+    HIP_TRY(hipGetDeviceCount(&have));
+    for (uint32_t r = 0; r < ndevices; ++r)
+        if (devices[r] < 0 || devices[r] >= have) {
+            set_err("device %d of the list does not exist (%d visible)", devices[r], have);
+            return RT_E_INVALID;
+        }
+    std::lock_guard<std::mutex> lk(g_mu);
+    int before = 0;
+    HIP_TRY(hipGetDevice(&before));
+    const uint32_t W = fb->width, H = fb->height, n = ndevices;
+    const uint32_t nblocks = (H + 7u) / 8u, per = (nblocks + n - 1u) / n;
+    const size_t local_px = (size_t)per * 8u * W;
+    const uint64_t samples = (uint64_t)local_px * cam->sqrtSpp * cam->sqrtSpp;
+    uint64_t want = samples * 2 < (1ull << 20) ? (1ull << 20) : samples * 2;
+    if (want > kDefaultCap)
+        want = kDefaultCap;
+
+    /* slots follow the list; a changed list starts over */
+    bool same = g_slots.size() == n;
+    for (uint32_t r = 0; same && r < n; ++r)
+        same = g_slots[r].device == devices[r];
+    if (!same) {
+        for (DevSlot &s : g_slots)
+            slot_release(s);
+        g_slots.assign(n, DevSlot());
+    }
+    int rc = 0;
+    for (uint32_t r = 0; r < n && !rc; ++r) { /* every device gets its share before anyone waits */
+        DevSlot &s = g_slots[r];
+        s.device = devices[r];
+        HIP_TRY(hipSetDevice(s.device));
+        if (s.ctx && s.ctx->cap < want) {
+            rt_hip_ctx_destroy(s.ctx);
+            s.ctx = nullptr;
+        }
+        if (!s.ctx && (rc = rt_hip_ctx_create(&s.ctx, s.device, want)))
+            break;
+        if (!s.stream)
+            HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        if ((rc = rt_hip_scene_upload(s.ctx, scene)))
+            break;
+        if (local_px > s.argb_px) {
+            if (s.d_argb) (void)hipFree(s.d_argb);
+            s.d_argb = nullptr; s.argb_px = 0;
+            HIP_TRY(hipMalloc((void **)&s.d_argb, local_px * sizeof(uint32_t)));
+            s.argb_px = local_px;
+        }
+        if (fb->radiance && local_px > s.rad_px) {
+            if (s.d_rad) (void)hipFree(s.d_rad);
+            s.d_rad = nullptr; s.rad_px = 0;
+            HIP_TRY(hipMalloc((void **)&s.d_rad, local_px * 3 * sizeof(float)));
+            s.rad_px = local_px;
+        }
+        rc = rt_hip_render_interleaved(s.ctx, cam, s.d_argb, fb->radiance ? s.d_rad : nullptr, r, n, s.stream);
+    }
+    for (uint32_t r = 0; r < n; ++r) { /* collect in list order; later devices keep rendering meanwhile */
+        DevSlot &s = g_slots[r];
+        if (!s.ctx || !s.ctx->pending)
+            continue;
+        const int rf = rt_hip_finish(s.ctx, nullptr);
+        if (!rc)
+            rc = rf;
+        if (rc)
+            continue;
+        HIP_TRY(hipSetDevice(s.device));
+        rc = copy_blocks_back(s, fb->argb, s.d_argb, sizeof(uint32_t), W, H, r, n);
+        if (!rc && fb->radiance)
+            rc = copy_blocks_back(s, fb->radiance, s.d_rad, 3 * sizeof(float), W, H, r, n);
+    }
+    for (uint32_t r = 0; r < n; ++r)
+        if (g_slots[r].stream) {
+            (void)hipSetDevice(g_slots[r].device);
+            const hipError_t e = hipStreamSynchronize(g_slots[r].stream);
+            if (e != hipSuccess && !rc) {
+                set_err("copying pixels back from device %d: %s", g_slots[r].device, hipGetErrorString(e));
+                rc = -(int)e;
+            }
+        }
+    (void)hipSetDevice(before);
+    return rc;
+}
+
+/* RT_HIP_DEVICES = "all" | "0,1,2,3": the device list raytrace() spreads a frame over (unset: the
+ * current device).  Returns the count written to out[]. */
+static uint32_t devices_from_env(int *out, uint32_t room)
+{
+    const char *env = getenv("RT_HIP_DEVICES");
+    if (!env || !*env)
+        return 0;
+    uint32_t n = 0;
+    if (!strcmp(env, "all")) {
+        int have = 0;
+        if (hipGetDeviceCount(&have) != hipSuccess)
+            return 0;
+        for (int d = 0; d < have && n < room; ++d)
+            out[n++] = d;
+        return n;
+    }
+    for (const char *p = env; *p && n < room;) {
+        char *end = nullptr;
+        const long d = strtol(p, &end, 10);
+        if (end == p)
+            break;
+        out[n++] = (int)d;
+        p = (*end == ',') ? end + 1 : end;
+        if (*end && *end != ',')
+            break;
+    }
+    return n;
+}
+
 void raytrace(unsigned int *buffer, rt_scene_t *scene, float fovY, float aspectRatio, float nearZ,
               float farZ, unsigned int width, unsigned int height, unsigned int samplesPerPixelSq,
               unsigned int depth)
@@ -942,7 +1116,9 @@ void raytrace(unsigned int *buffer, rt_scene_t *scene, float fovY, float aspectR
     fb.height = height;
     fb.row0 = 0;
     fb.nrows = height;
-    const int rc = rt_hip_render(&view, &cam, &fb);
+    int devs[64];
+    const uint32_t ndev = devices_from_env(devs, 64);
+    const int rc = ndev > 1 ? rt_hip_render_devices(&view, &cam, &fb, devs, ndev) : rt_hip_render(&view, &cam, &fb);
     if (rc) {
         fprintf(stderr, "raytrace (HIP): error %d: %s\n", rc, rt_hip_last_error());
         exit(1);

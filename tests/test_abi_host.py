@@ -250,3 +250,19 @@ def test_scene_file_loader_grammar_and_errors(tmp_path, capfd):
         assert why in capfd.readouterr().out
     with pytest.raises(ValueError):
         rt.load_scene(str(tmp_path / "missing"))
+
+
+def test_command_line_host_keeps_the_reference_messages(tmp_path):
+    """raytracer_amd/rt (csrc/rt_main.c): main.c:127-131 and :153-157 - neither path touches a GPU."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(rt.__file__), "rt")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    p = subprocess.run([exe, "out.ppm", "scene"], capture_output=True, text=True)
+    assert p.returncode == 1
+    assert p.stdout == "raytrace outputFile sceneFile imgWidth imgHeight samplesPerPixel^2 depth\n"
+    p = subprocess.run([exe, str(tmp_path / "o.ppm"), str(tmp_path / "missing"), "8", "8", "1", "1"],
+                       capture_output=True, text=True)
+    assert p.returncode == 1
+    assert "Running Ray Tracer...\n" in p.stdout and p.stdout.endswith("Error parsing scene file.  Exiting...\n")
+    p = subprocess.run([exe, "o.ppm", "scene", "8", "8", "1", "1", "--frobnicate"], capture_output=True, text=True)
+    assert p.returncode == 1 and "unknown option" in p.stdout

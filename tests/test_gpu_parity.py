@@ -130,6 +130,64 @@ def test_sparse_pixels_of_full_size_builtin_configs(golden, make_scene):
         assert (rel <= 1e-4).mean() >= 0.99, sp["key"]
 
 
+@pytest.mark.parametrize("W,H,s,d,devs", [(333, 217, 2, 5, [0, 0, 0]), (640, 480, 1, 4, [0, 0]),
+                                          (64, 20, 1, 3, [0, 0, 0, 0, 0]), (96, 64, 2, 4, [0])])
+def test_device_list_render_equals_the_single_device_render(make_scene, W, H, s, d, devs):
+    """rt_hip_render_devices: cyclic 8-row blocks over a device list, copied straight into the host
+    frame.  One GPU here, so the list names it several times (one context and stream per entry): the
+    partition, the strided copies and the ragged last block are what is under test.  217 rows = 27
+    blocks + 1 row; 20 rows over 5 entries leaves two entries without a block."""
+    sc = make_scene("builtin")
+    cam = rt.prepare_camera(sc, W, H, s, d)
+    a1, r1 = rt.render(sc, cam)
+    a2, r2 = rt.render(sc, cam, devices=devs)
+    assert np.array_equal(a1, a2)
+    assert np.array_equal(r1.view(np.uint32), r2.view(np.uint32))
+    a3, _ = rt.render(sc, cam, devices=devs, want_radiance=False)   # cached slots, no radiance buffer
+    assert np.array_equal(a1, a3)
+    with pytest.raises(_lib.RtHipError):
+        rt.render(sc, cam, devices=[0, 99])
+    with pytest.raises(_lib.RtHipError):
+        rt.render(sc, cam, row0=8, nrows=8, devices=[0, 0])
+
+
+def test_raytrace_spreads_over_the_devices_the_environment_names(golden, monkeypatch):
+    meta, arrays = golden
+    sc = rt.Scene.builtin()
+    W, H = 640, 480
+    monkeypatch.setenv("RT_HIP_DEVICES", "0,0,0")
+    buf = np.zeros(W * H, dtype=np.uint32)
+    rt.raytrace(buf, sc, 45.0, W / H, 1.0, 200.0, W, H, 1, 4)
+    monkeypatch.delenv("RT_HIP_DEVICES")
+    one = np.zeros(W * H, dtype=np.uint32)
+    rt.raytrace(one, sc, 45.0, W / H, 1.0, 200.0, W, H, 1, 4)
+    assert np.array_equal(buf, one)
+
+
+def test_command_line_host(golden, tmp_path):
+    """raytracer_amd/rt: the reference's argv contract and messages (main.c:96-173) plus --devices,
+    --load-scene and --dump-radiance.  The P6 file of config 1 must have the reference's md5."""
+    import hashlib, os, subprocess
+    meta, arrays = golden
+    fr = [f for f in meta["frames"] if (f["W"], f["H"], f["sqrtSpp"], f["depth"]) == (640, 480, 1, 4)][0]
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = os.path.join(os.path.dirname(rt.__file__), "rt")
+    scene = os.path.join(here, "golden", "whitted.scene")
+    out, out2, radf = tmp_path / "a.ppm", tmp_path / "b.ppm", tmp_path / "b.f32"
+    p = subprocess.run([exe, str(out), scene, "640", "480", "1", "4"], capture_output=True, text=True, timeout=110)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert p.stdout.startswith("Running Ray Tracer...\n") and "Run time:\t" in p.stdout
+    assert hashlib.md5(out.read_bytes()).hexdigest() == fr["md5"]
+    p = subprocess.run([exe, str(out2), scene, "640", "480", "1", "4", "--load-scene", "--devices", "0,0,0",
+                        "--dump-radiance", str(radf)], capture_output=True, text=True, timeout=110)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert out2.read_bytes() == out.read_bytes()      # whitted.scene describes the built-in scene
+    rad = np.fromfile(radf, dtype=np.float32).reshape(480, 640, 3)
+    sc = rt.Scene.builtin()
+    _, want = rt.render(sc, rt.prepare_camera(sc, 640, 480, 1, 4))
+    assert np.array_equal(rad.view(np.uint32), want.view(np.uint32))
+
+
 def test_empty_scene_and_no_lights():
     sc = rt.Scene.builtin()
     n_obj, n_l = sc.c.nObjects, sc.c.nLights
