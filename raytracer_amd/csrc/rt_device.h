@@ -168,6 +168,7 @@ void rt_launch_fold(const DevWork &Wk, uint32_t level, uint32_t expect, hipStrea
 void rt_launch_resolve(const DevCamera &C, const DevWork &Wk, const DevRows &R, uint32_t *d_argb,
                        float *d_radiance, hipStream_t stream);
 size_t rt_scene_lds_bytes(const DevScene &S);
+int rt_scene_shape(const DevScene &S); /* 0 = generic kernels, else the specialisation (rt_kernels.hip) */
 void rt_launch_publish(uint32_t *counters, uint32_t *mirror, uint32_t words, hipStream_t stream);
 void rt_launch_deinterleave(const uint32_t *gathered, uint32_t *frame, uint32_t width, uint32_t height,
                             uint32_t nphases, hipStream_t stream);

@@ -1,10 +1,11 @@
+import re
 #!/usr/bin/env python3
 """Per-kernel timeline of the last full frame in a rocprofv3 --kernel-trace directory."""
 import csv, glob, sys
 d = sys.argv[1]
 rows = list(csv.DictReader(open(glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0])))
 ks = sorted((r for r in rows if "k_" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(ks) if "k_primary<" in r["Kernel_Name"] and ", true, " not in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(ks) if "k_primary<" in r["Kernel_Name"] and not re.search(r"k_primary<\w+, true,", r["Kernel_Name"])]
 s, e = idx[-2], idx[-1]
 t0 = int(ks[s]["Start_Timestamp"])
 for r in ks[s:e]:
