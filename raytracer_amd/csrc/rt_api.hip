@@ -676,7 +676,8 @@ int rt_hip_scene_upload(rt_hip_ctx *c, const rt_scene *sc)
     S.tabSlots = (uint32_t)tab.size();
     S.tabInLds = 0;
     S.tabInLds = (nSph <= RT_TILE_SPHERES &&
-                  rt_scene_lds_bytes(S) - RT_PARK_FLOATS * sizeof(float) + tab.size() * sizeof(float4) <=
+                  rt_scene_lds_bytes(S) - RT_PARK_FLOATS * sizeof(float) +
+                          (tab.size() + nSph + nPoly) * sizeof(float4) /* tables + k_primary's eye terms */ <=
                       RT_LDS_TABLE_BUDGET) ? 1u : 0u;
     S.bg[0] = sc->bgColor.r; S.bg[1] = sc->bgColor.g; S.bg[2] = sc->bgColor.b;
     S.ambient[0] = sc->ambientLightColor.r;

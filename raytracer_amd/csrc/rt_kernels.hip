@@ -480,12 +480,17 @@ __device__ __forceinline__ void block_copy(float4 *dst, const float4 *src, uint3
  * TILED: the sphere list does not fit one LDS tile; the tile loop contains block barriers, so
  * every thread of the block must call this function (inactive lanes pass active=false).
  */
-template <bool TILED, bool FILTERED, bool ANYHIT, bool STATS, bool BIG>
+template <bool TILED, bool FILTERED, bool ANYHIT, bool STATS, bool BIG, bool EYE = false>
 __device__ __forceinline__ void intersect_all(const DevScene &S, const float4 *lds_poly,
                                               float4 *lds_sph, bool active, const Ray &r,
                                               uint32_t exc_sph, uint32_t exc_poly, float &out_d,
-                                              uint32_t &out_obj, Tally<STATS> &tl)
+                                              uint32_t &out_obj, Tally<STATS> &tl,
+                                              const float4 *eye_terms = nullptr)
 {
+    /* EYE: the ray starts at the eye, like every primary ray, so the terms of the tests that depend on
+     * the origin alone were evaluated once per block by stage_eye_terms (same expressions, same
+     * rounding): (o - c, 4*(|o - c|^2 - r^2)) per sphere, -(n.o + F) per polygon. */
+    static_assert(!EYE || (!TILED && !BIG && !FILTERED), "eye terms: small untiled scenes, primary rays");
     float d = 0.0f;
     uint32_t best_k = RT_NONE; /* winning sphere-list index */
     bool found = false;
@@ -500,6 +505,10 @@ __device__ __forceinline__ void intersect_all(const DevScene &S, const float4 *l
         if (active && !(ANYHIT && !STATS && found)) {
             /* one sphere against this lane's ray: ray.c:185-195 up to the discriminant */
             auto discriminant = [&](const float4 s, float &B) -> float {
+                if (EYE) { /* s = (ex, ey, ez, 4*Cq) */
+                    B = 2.0f * ((r.dx * s.x + r.dy * s.y) + r.dz * s.z);
+                    return (B * B) - s.w;
+                }
                 const float ex = r.ox - s.x, ey = r.oy - s.y, ez = r.oz - s.z;
                 B = 2.0f * ((r.dx * ex + r.dy * ey) + r.dz * ez);
                 const float Cq = ((ex * ex + ey * ey) + ez * ez) - s.w;
@@ -562,7 +571,7 @@ __device__ __forceinline__ void intersect_all(const DevScene &S, const float4 *l
             }
             if (!(BIG && ANYHIT && !STATS && found)) {
                 for (; j < cnt; ++j) {
-                    const float4 s = lds_sph[j]; /* same address in all lanes: LDS broadcast */
+                    const float4 s = EYE ? eye_terms[j] : lds_sph[j]; /* same address in all lanes: LDS broadcast */
                     if (FILTERED && (t0 + j) == exc_sph)
                         continue;
                     tl.sph_test();
@@ -593,7 +602,8 @@ __device__ __forceinline__ void intersect_all(const DevScene &S, const float4 *l
             tl.poly_test();
             const float4 pl = lds_poly[p];
             /* ray.c:92-117 */
-            const float num = -1.0f * (dot3(pl.x, pl.y, pl.z, r.ox, r.oy, r.oz) + pl.w);
+            const float num = EYE ? eye_terms[S.nSph + p].x
+                                  : -1.0f * (dot3(pl.x, pl.y, pl.z, r.ox, r.oy, r.oz) + pl.w);
             const float den = dot3(pl.x, pl.y, pl.z, r.dx, r.dy, r.dz);
             if (den == 0.0f) {
                 tl.poly_par();
@@ -672,6 +682,26 @@ __device__ __forceinline__ void stage_colours(const DevScene &S, float *kc)
             kc[KC_BG + k] = S.bg[k];
             kc[KC_AMBIENT + k] = S.ambient[k];
         }
+}
+
+/* The origin-only terms of the ray-object tests for rays that start at the eye (intersect_all<EYE>):
+ * ray.c:185-195 and ray.c:92-95 with origin = eye.  Needs lds_sph / lds_poly staged (barrier before),
+ * callers follow up with __syncthreads(). */
+__device__ __forceinline__ void stage_eye_terms(const DevScene &S, const DevCamera &C, const float4 *lds_poly,
+                                                const float4 *lds_sph, float4 *eye_terms)
+{
+    const float ox = C.eye[0], oy = C.eye[1], oz = C.eye[2];
+    for (uint32_t k = threadIdx.x; k < S.nSph + S.nPoly; k += RT_BLOCK) {
+        if (k < S.nSph) {
+            const float4 s = lds_sph[k];
+            const float ex = ox - s.x, ey = oy - s.y, ez = oz - s.z;
+            const float Cq = ((ex * ex + ey * ey) + ez * ez) - s.w;
+            eye_terms[k] = make_float4(ex, ey, ez, 4.0f * Cq);
+        } else {
+            const float4 pl = lds_poly[k - S.nSph];
+            eye_terms[k] = make_float4(-1.0f * (dot3(pl.x, pl.y, pl.z, ox, oy, oz) + pl.w), 0.f, 0.f, 0.f);
+        }
+    }
 }
 
 /* counter line of (level, shard): low word = nodes made at `level`, high word = rays queued
@@ -1252,6 +1282,12 @@ __global__ __launch_bounds__(RT_BLOCK, (TABLDS ? 6 : RT_WPE)) void k_primary(Dev
             ((uint32_t *)(lds_sph + S.nSph))[k] = S.sph_obj[k];
     }
     __syncthreads();
+    float4 *eye_terms = nullptr;
+    if constexpr (TABLDS) { /* small scenes: behind the shading tables */
+        eye_terms = (float4 *)(lds_vis + vis_words(S.nLights)) + S.tabSlots;
+        stage_eye_terms(S, C, lds_poly, lds_sph, eye_terms);
+        __syncthreads();
+    }
 
     /* a wave owns an 8x8 pixel tile; the block is 4 tiles side by side (32x8 pixels) */
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
@@ -1283,8 +1319,8 @@ __global__ __launch_bounds__(RT_BLOCK, (TABLDS ? 6 : RT_WPE)) void k_primary(Dev
 
             float d;
             uint32_t obj;
-            intersect_all<TILED, false, false, STATS, !TABLDS>(S, lds_poly, lds_sph, valid, r, RT_NONE, RT_NONE,
-                                                      d, obj, tl);
+            intersect_all<TILED, false, false, STATS, !TABLDS, TABLDS>(S, lds_poly, lds_sph, valid, r, RT_NONE,
+                                                              RT_NONE, d, obj, tl, eye_terms);
             const bool hit = valid && (obj != RT_NONE);
             float leaf[3] = {kc[KC_BG + 0], kc[KC_BG + 1], kc[KC_BG + 2]}; /* miss: raytrace.c:700-703 */
             uint32_t node;
@@ -1611,7 +1647,7 @@ size_t rt_scene_lds_bytes(const DevScene &S)
      * + the light / object tables when they are staged */
     return RT_PARK_FLOATS * sizeof(float) + (size_t)(S.nPolySlots + sph) * sizeof(float4) +
            (size_t)vis_words(S.nLights) * sizeof(uint32_t) +
-           (S.tabInLds ? (size_t)S.tabSlots * sizeof(float4) : 0);
+           (S.tabInLds ? (size_t)(S.tabSlots + S.nSph + S.nPoly) * sizeof(float4) : 0); /* + eye terms */
 }
 
 void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
