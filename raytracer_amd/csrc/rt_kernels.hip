@@ -1542,25 +1542,31 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DevCamera C, DevWork Wk, D
         const float4 acc = Wk.pixAcc[p];
         float r = acc.x, g = acc.y, b = acc.z;
         const uint32_t nroots = __float_as_uint(acc.w);
-        /* four roots at a time: ids first, then all their node words, then the sums in root order */
-        for (uint32_t k = 0; k < nroots; k += 4u) {
-            uint32_t id[4];
+        /* sixteen root ids at a time (one round trip for a whole 4x4-sample pixel), then their node
+         * words four roots at a time, all loads of a step independent; the sums in root order */
+        for (uint32_t k0 = 0; k0 < nroots; k0 += 16u) {
+            uint32_t id[16];
 #pragma unroll
-            for (uint32_t u = 0; u < 4u; ++u)
-                id[u] = Wk.roots[(size_t)min(k + u, nroots - 1u) * npix + p];
-            float4 A[4], cr[4], ct[4];
-            float2 K[4];
+            for (uint32_t u = 0; u < 16u; ++u)
+                id[u] = Wk.roots[(size_t)min(k0 + u, nroots - 1u) * npix + p];
 #pragma unroll
-            for (uint32_t u = 0; u < 4u; ++u) {
-                const uint32_t j = id[u] < Wk.cap ? id[u] : 0u;
-                A[u] = Wk.nodeA()[j]; K[u] = Wk.nodeK()[j]; cr[u] = Wk.childR()[j]; ct[u] = Wk.childT()[j];
-            }
+            for (uint32_t g4 = 0; g4 < 16u; g4 += 4u) {
+                if (k0 + g4 >= nroots)
+                    break;
+                float4 A[4], cr[4], ct[4];
+                float2 K[4];
 #pragma unroll
-            for (uint32_t u = 0; u < 4u; ++u) {
-                if (k + u < nroots && id[u] < Wk.cap) {
-                    float c[3];
-                    fold_values(A[u], K[u], cr[u], ct[u], c);
-                    r = r + c[0]; g = g + c[1]; b = b + c[2];
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    const uint32_t j = id[g4 + u] < Wk.cap ? id[g4 + u] : 0u;
+                    A[u] = Wk.nodeA()[j]; K[u] = Wk.nodeK()[j]; cr[u] = Wk.childR()[j]; ct[u] = Wk.childT()[j];
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    if (k0 + g4 + u < nroots && id[g4 + u] < Wk.cap) {
+                        float c[3];
+                        fold_values(A[u], K[u], cr[u], ct[u], c);
+                        r = r + c[0]; g = g + c[1]; b = b + c[2];
+                    }
                 }
             }
         }
