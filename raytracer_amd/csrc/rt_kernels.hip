@@ -432,11 +432,12 @@ __device__ __forceinline__ bool polygon_inside(const float4 *vtx, uint32_t nv, f
     return polygon_inside_exact(vtx, nv, px, py, pz);
 }
 
-/* powf(s, ke) of raytrace.c:371.  glibc's powf evaluates in double and is correctly rounded in
- * all but astronomically rare cases; for the usual integral shininess (ke = 2, 20, ...) the same
- * value comes from a square-and-multiply chain in double (relative error < 2^-49) rounded once to
- * float - exact where the device's float powf can be an ulp off, and much shorter.  Other
- * exponents use the device powf (<= 1 ulp). */
+/* powf(s, ke) of raytrace.c:371.  For the usual integral shininess (ke = 2, 20, ...) the power is a
+ * square-and-multiply chain in double (relative error < 2^-49) rounded once to float: the CORRECTLY
+ * rounded value.  glibc 2.35's powf is only faithfully rounded - it returns the neighbouring float
+ * for ~0.07 % of arguments - and that is the one last-bit difference left between these kernels and
+ * the reference (tests: test_radiance_is_bit_identical_but_for_libm_powf).  Other exponents use the
+ * device powf (<= 1 ulp). */
 __device__ __forceinline__ float phong_pow(float s, float ke)
 {
     const int e = (int)ke;
