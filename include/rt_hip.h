@@ -228,6 +228,28 @@ int  rt_hip_render_interleaved(rt_hip_ctx *ctx, const rt_camera *camera,
 int  rt_hip_deinterleave(const uint32_t *d_gathered, uint32_t *d_frame, uint32_t width, uint32_t height,
                          uint32_t nphases, void *stream);
 
+/* Tone reproduction -- apply_tone / ward_tone / reinhard_tone, raytrace.c:792-871: the step the
+ * reference keeps between its pixel loop and the 8-bit pack (its call is commented out at
+ * raytrace.c:917).  d_radiance: DEVICE frame of 3 floats per pixel as the render calls write it,
+ * changed in place; d_argb (may be NULL) is re-packed from it (raytrace.c:783-790).
+ * op: RT_TONE_WARD (what apply_tone does, :861) or RT_TONE_REINHARD (reinhard_tone in its place;
+ * key_pixel < 0: log-average key, else that pixel's luminance, :816-819).  ldMax / lMax: scene_t's
+ * display and scene luminance maxima (scene.h:42-43).  Asynchronous.  The two frame-wide sums are
+ * double tree sums, not the reference's float running sums (which lose ~3e-4 at 2 M pixels).
+ * The calls share one per-device scratch block: calls that overlap on one GPU race. */
+#define RT_TONE_WARD      1
+#define RT_TONE_REINHARD  2
+int  rt_hip_tone(float *d_radiance, uint32_t *d_argb, uint64_t npixels, int op, float ldMax, float lMax,
+                 int64_t key_pixel, void *stream);
+/* The same in two halves for frames that are spread over several GPUs: each rank sums its own pixels
+ * into d_sums (3 doubles on the device: sum L, sum log(1e-5 + L), L of the key pixel if this rank
+ * holds it, else 0), the ranks all-reduce (SUM) those 3 doubles - the path's only data exchange
+ * besides the frame gather - and each applies the operator to its pixels with the frame's pixel count. */
+int  rt_hip_tone_sums(const float *d_radiance, uint64_t npixels, float lMax, int64_t key_pixel,
+                      double *d_sums, void *stream);
+int  rt_hip_tone_apply(float *d_radiance, uint32_t *d_argb, uint64_t npixels, int op, float ldMax,
+                       float lMax, const double *d_sums, uint64_t total_pixels, int use_key, void *stream);
+
 /* Wait for the last rt_hip_render_rows, verify no queue overflowed (re-rendering finer
  * batches if one did) and return its counters.  stats may be NULL. */
 int  rt_hip_finish(rt_hip_ctx *ctx, rt_hip_stats *stats);

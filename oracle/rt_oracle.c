@@ -557,3 +557,66 @@ void rt_oracle_ray_create(const float p1[3], const float p2[3], float out[7])
 }
 
 size_t rt_oracle_counts_size(void) { return sizeof(rt_oracle_counts); }
+
+/* ---- tone reproduction: apply_tone / ward_tone / reinhard_tone -- raytrace.c:792-871 ------------
+ * The step the reference keeps between its pixel loop and the 8-bit pack (the call is commented
+ * out at raytrace.c:917).  rgb: n pixels of 3 floats (the reference's colorbuffer), changed in
+ * place.  op 1 = Ward (what apply_tone calls, :861), op 2 = Reinhard (reinhard_tone, :808-831, put in
+ * ward_tone's place; key_pixel < 0: log-average key, else the luminance of that pixel, :816-819).
+ * All sums are float and sequential, in pixel order, as in the reference.  sums_out (may be NULL)
+ * receives totalLum, totalLogLum. */
+static float luminance(const float *c) { return 0.27f * c[0] + 0.67f * c[1] + 0.06f * c[2]; } /* color.c:168-173 */
+/* DIAGNOSTIC switch (off by default): the two frame-wide sums in double instead of the reference's
+ * float running sums.  At 2 M pixels the float sum of log-luminances has an ulp of 1 against terms
+ * of ~6, so the reference's own total is off by percents (2.4 % in the Ward factor at 1920x1080);
+ * the HIP kernels sum in double, and the full-size test compares them with this variant. */
+static int g_tone_wide_sums;
+void rt_oracle_set_tone_wide_sums(int on) { g_tone_wide_sums = on; }
+
+void rt_oracle_tone(float *rgb, uint64_t n, int op, float ldMax, float lMax, int64_t key_pixel,
+                    float sums_out[2])
+{
+    const float ldMaxInv = 1.0f / ldMax; /* :838 */
+    float totalLum = 0.0f, totalLogLum = 0.0f;
+    double wideLum = 0.0, wideLogLum = 0.0;
+    const float delta = .00001f;
+    for (uint64_t i = 0; i < n; ++i) { /* :851-859 */
+        float *c = rgb + 3 * i;
+        c[0] = c[0] * lMax; c[1] = c[1] * lMax; c[2] = c[2] * lMax;
+        const float l = luminance(c);
+        totalLum += l;
+        totalLogLum += logf(delta + l);
+        wideLum += (double)l;
+        wideLogLum += (double)logf(delta + l);
+    }
+    if (g_tone_wide_sums) {
+        totalLum = (float)wideLum;
+        totalLogLum = (float)wideLogLum;
+    }
+    if (sums_out) {
+        sums_out[0] = totalLum;
+        sums_out[1] = totalLogLum;
+    }
+    const float logAvgLum = expf((1.0f / (float)n) * totalLogLum); /* :795, :811 */
+    if (op == 2) {
+        float scale = 0.18f / logAvgLum; /* :814 */
+        if (key_pixel > -1)
+            scale = 0.18 / luminance(rgb + 3 * key_pixel); /* :818: a double quotient stored to float */
+        for (uint64_t i = 0; i < n; ++i) { /* :821-830 */
+            float *c = rgb + 3 * i;
+            for (int k = 0; k < 3; ++k) {
+                c[k] = c[k] * scale;
+                c[k] = (c[k] * ldMax) / (1.0f + c[k]);
+            }
+        }
+    } else {
+        const float sf = powf((1.219f + powf(ldMax / 2.0f, 0.4f)) / (1.219f + powf(logAvgLum, 0.4f)), 2.5f); /* :797-798 */
+        for (uint64_t i = 0; i < 3 * n; ++i)
+            rgb[i] = rgb[i] * sf; /* :801-805 */
+    }
+    for (uint64_t i = 0; i < 3 * n; ++i) { /* back to the display model, clamped: :865-868 */
+        rgb[i] = rgb[i] * ldMaxInv;
+        if (rgb[i] > 1.0f)
+            rgb[i] = 1.0f;
+    }
+}

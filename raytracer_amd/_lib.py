@@ -16,7 +16,7 @@ EXPORTS = [
     "rt_hip_ctx_set_timing", "rt_hip_ctx_set_batch_samples", "rt_hip_last_error", "rt_hip_version",
     "rt_poly_plane", "rt_scene_builtin", "rt_parse_scene", "rt_scene_free", "rt_scene_synthetic",
     "rt_write_image", "write_image", "rt_hip_selftest_arith", "rt_load_scene", "rt_hip_deinterleave",
-    "rt_hip_render_devices",
+    "rt_hip_render_devices", "rt_hip_tone", "rt_hip_tone_sums", "rt_hip_tone_apply",
 ]
 
 _lib = None
@@ -43,6 +43,12 @@ def load():
     lib.rt_hip_render.restype = i32
     lib.rt_hip_render_devices.argtypes = [P(A.rt_scene), P(A.rt_camera), P(A.rt_framebuffer), P(C.c_int), u32]
     lib.rt_hip_render_devices.restype = i32
+    lib.rt_hip_tone.argtypes = [vp, vp, u64, i32, f32, f32, C.c_int64, vp]
+    lib.rt_hip_tone.restype = i32
+    lib.rt_hip_tone_sums.argtypes = [vp, u64, f32, C.c_int64, vp, vp]
+    lib.rt_hip_tone_sums.restype = i32
+    lib.rt_hip_tone_apply.argtypes = [vp, vp, u64, i32, f32, f32, vp, u64, i32, vp]
+    lib.rt_hip_tone_apply.restype = i32
     lib.rt_camera_prepare.argtypes = [P(A.rt_camera), P(A.rt_scene_t), C.c_uint, C.c_uint, C.c_uint, f32, f32, f32, C.c_uint]
     lib.rt_camera_prepare.restype = None
     lib.rt_hip_ctx_create.argtypes = [P(vp), i32, u64]

@@ -117,6 +117,24 @@ def render(scene, cam, row0=0, nrows=None, want_radiance=True, devices=None):
     return argb, rad
 
 
+TONE_WARD, TONE_REINHARD = 1, 2
+
+
+def tone(d_radiance, d_argb, npixels, op, ld_max, l_max, key_pixel=-1, stream=0):
+    """rt_hip_tone: apply_tone (raytrace.c:792-871) on a DEVICE radiance frame, in place; d_argb may be 0."""
+    check(load().rt_hip_tone(d_radiance, d_argb or None, npixels, op, ld_max, l_max, key_pixel, stream or None),
+          "rt_hip_tone")
+
+
+def tone_sums(d_radiance, npixels, l_max, key_pixel, d_sums, stream=0):
+    check(load().rt_hip_tone_sums(d_radiance, npixels, l_max, key_pixel, d_sums, stream or None), "rt_hip_tone_sums")
+
+
+def tone_apply(d_radiance, d_argb, npixels, op, ld_max, l_max, d_sums, total_pixels, use_key=False, stream=0):
+    check(load().rt_hip_tone_apply(d_radiance, d_argb or None, npixels, op, ld_max, l_max, d_sums, total_pixels,
+                                   int(bool(use_key)), stream or None), "rt_hip_tone_apply")
+
+
 def write_image(filename, buffer, width, height):
     """output.h:15-16 - raw P6; returns 1 on success, 0 on failure like the reference."""
     buf = np.ascontiguousarray(buffer, dtype=np.uint32)

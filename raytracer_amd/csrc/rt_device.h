@@ -18,7 +18,7 @@
 /* per-thread parking area at the start of every trace kernel's LDS (row-major [word][thread],
  * conflict-free; rows listed in shade_and_spawn).  Values parked here do not occupy VGPRs across
  * the intersection searches. */
-#define RT_PARK_WORDS   22u
+#define RT_PARK_WORDS   20u
 #define RT_PARK_FLOATS  (RT_PARK_WORDS * RT_BLOCK)
 
 /* Camera constants, pre-folded on the host with the reference's float rounding

@@ -35,6 +35,9 @@
 #define RT_SPHERES_PER_TRIP 8u
 #endif
 #ifndef RT_WPE
+#ifndef RT_WPE_SHAPE1
+#define RT_WPE_SHAPE1 6
+#endif
 #define RT_WPE 1 /* min waves per SIMD asked of the register allocator (launch_bounds 2nd arg) */
 #endif
 
@@ -992,7 +995,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
      *   0-6   transmission ray (o, d, magnitude) - over the eye ray k_bounce parked there, which
      *         is not needed once both rays exist
      *   7-16  the reflection child's queue entry (point, object, ray origin, ray direction)
-     *   17-21 local colour, kr, kt                                                          */
+     *   17-19 local colour (kr, kt are read again from the object's record afterwards)      */
     float *const park = lds_park + threadIdx.x;
     Ray cr; /* the child ray being traced: the reflection ray first */
     cr.ox = cr.oy = cr.oz = cr.dx = cr.dy = cr.dz = cr.mag = 0.0f;
@@ -1034,7 +1037,6 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
         park[3 * RT_BLOCK] = tr.dx; park[4 * RT_BLOCK] = tr.dy; park[5 * RT_BLOCK] = tr.dz;
         park[6 * RT_BLOCK] = tr.mag;
         park[17 * RT_BLOCK] = outr; park[18 * RT_BLOCK] = outg; park[19 * RT_BLOCK] = outb;
-        park[20 * RT_BLOCK] = kr; park[21 * RT_BLOCK] = kt;
     }
     bool hit_r = false, hit_t = false;
     float cd = 0.0f;
@@ -1073,7 +1075,10 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
         asm volatile("" : "+v"(t)); /* opaque index: the compiler must not keep the parked values in registers */
         const float *back = lds_park + t;
         outr = back[17 * RT_BLOCK]; outg = back[18 * RT_BLOCK]; outb = back[19 * RT_BLOCK];
-        kr2 = back[20 * RT_BLOCK]; kt2 = back[21 * RT_BLOCK];
+        uint32_t rec2 = rec; /* kr, kt: read again from the object's record rather than parked */
+        asm volatile("" : "+v"(rec2));
+        const float4 mC2 = tab[rec2 + RT_OBJ_PHONG];
+        kr2 = mC2.z; kt2 = mC2.w;
     }
     if (!(hit_r || hit_t)) {
         /* every child (if any) left the scene: the node is finished.  Same expression order as
@@ -1262,7 +1267,7 @@ template <> __device__ __forceinline__ void fix_shape<1>(DevScene &S)
 /* k_primary: get_pixel_color + get_ray_color + depth-0 get_shade_color_phong, fused           */
 /* ------------------------------------------------------------------------------------------ */
 template <bool TILED, bool STATS, bool TABLDS, int SHAPE>
-__global__ __launch_bounds__(RT_BLOCK, (TABLDS ? 6 : RT_WPE)) void k_primary(DevScene S, DevCamera C, DevWork Wk,
+__global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 : RT_WPE)) void k_primary(DevScene S, DevCamera C, DevWork Wk,
                                                       DevRows R)
 {
     fix_shape<SHAPE>(S);

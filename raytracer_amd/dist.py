@@ -88,3 +88,24 @@ class FrameGather:
                        "rt_hip_deinterleave")
             return self.frame
         return deinterleave(self.gathered, self.plan, out=self.frame)
+
+
+def tone_slices(local_radiance, local_argb, local_pixels, total_pixels, op, ld_max, l_max, key_pixel_local=-1,
+                use_key=False, group=None):
+    """The tone-reproduction step (apply_tone, raytrace.c:792-871) on a frame whose pixels are spread
+    over the ranks - the one exchange step of the path: every rank sums the luminance and
+    log-luminance of its own `local_pixels` (the valid prefix of its compact buffer), the 3 doubles are
+    all-reduced (RCCL), every rank applies the operator to its pixels.  key_pixel_local: index of
+    Reinhard's key pixel inside THIS rank's buffer, or -1 on the ranks that do not hold it;
+    use_key says whether a key pixel is used at all (the same on every rank)."""
+    import torch.distributed as dist
+    from . import api
+    sums = torch.zeros(3, dtype=torch.float64, device=local_radiance.device)
+    api.tone_sums(local_radiance.data_ptr(), local_pixels, l_max, key_pixel_local, sums.data_ptr(),
+                  torch.cuda.current_stream(local_radiance.device).cuda_stream)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    api.tone_apply(local_radiance.data_ptr(), local_argb.data_ptr() if local_argb is not None else 0, local_pixels,
+                   op, ld_max, l_max, sums.data_ptr(), total_pixels, use_key,
+                   torch.cuda.current_stream(local_radiance.device).cuda_stream)
+    return sums

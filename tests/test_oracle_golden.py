@@ -1,6 +1,7 @@
 """The CPU oracle (oracle/rt_oracle.c) must reproduce the REFERENCE's outputs bit for bit.
 The fixtures were produced by running the untouched reference (tests/golden/make_golden.py)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -144,3 +145,18 @@ def test_slab_and_threads_do_not_change_pixels(make_scene):
     assert np.array_equal(a1, a8) and np.array_equal(r1, r8) and c1 == c8
     a_s, r_s, _ = O.render(sc.c, cam, row0=24, nrows=16, nthreads=2)
     assert np.array_equal(a_s[24:40], a1[24:40]) and not a_s[:24].any() and not a_s[40:].any()
+
+
+def test_tone_step_equals_the_reference_bit_for_bit(golden):
+    """rt_oracle_tone against apply_tone / reinhard_tone of the compiled reference (raytrace.c:792-871),
+    fixtures made by tests/golden/make_golden_tone.py."""
+    import json
+    _, arrays = golden
+    here = os.path.dirname(os.path.abspath(__file__))
+    want = np.load(os.path.join(here, "golden", "tone.npz"))
+    cases = json.load(open(os.path.join(here, "golden", "tone.json")))["cases"]
+    assert len(cases) == 10
+    for c in cases:
+        out, sums = O.tone(arrays[c["input"]], c["op"], c["ldMax"], c["lMax"], c["keyPix"])
+        assert np.array_equal(out.view(np.uint32), want[c["key"]].view(np.uint32)), c["key"]
+        assert np.isfinite(sums).all()
