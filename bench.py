@@ -123,7 +123,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=30)  # the clocks settle over the first ~20 frames
     ap.add_argument("--sqrt-spp", type=int, default=4)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--inflight", type=int, default=2,
