@@ -133,10 +133,10 @@ def main():
     ap.add_argument("--overlap", action="store_true",
                     help="give every in-flight frame its own stream (kernels of neighbouring frames overlap; the "
                          "event-timed k_primary duration then includes the sharing and is not a clean roofline input)")
-    ap.add_argument("--gather-stream", choices=["side", "same"], default="same",
-                    help="N > 1: run the all-gather + de-interleave on the render stream, or on a second stream "
-                         "behind events (overlaps the next frame's render, but every cross-stream hand-over costs "
-                         "~0.1 ms of queue latency on this runtime: measured slower in the one-GPU rehearsal)")
+    ap.add_argument("--gather-stream", choices=["side", "same"], default="side",
+                    help="N > 1: run the all-gather + de-interleave on a second stream behind events, so that they "
+                         "overlap the next frame's render (default), or on the render stream (the frames then wait "
+                         "for their gathers: step = render + collective)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -180,8 +180,8 @@ def main():
         gathers.append(FrameGather(plan, W, torch.int32, dev, rank=rank))  # 0xFFRRGGBB bit patterns
 
     # N > 1: the in-place all-gather of frame k and its de-interleave copy (the library's streaming
-    # kernel) follow the render on the same stream; --gather-stream side moves them behind an event
-    # onto a second stream so that they overlap frame k+1.
+    # kernel) run on a second stream behind an event, overlapping the render of frame k+1
+    # (--gather-stream same keeps them on the render stream).
     comm = (torch.cuda.Stream(device=dev) if args.gather_stream == "side" else shared) if world > 1 else None
     rendered = [torch.cuda.Event() for _ in range(inflight)]
     gathered = [torch.cuda.Event() for _ in range(inflight)]
