@@ -295,6 +295,12 @@ def main():
                          "algorithmic_flop_per_launch": flops_k0 / max(launches_per_step, 1),
                          "avg_launch_ms": k0_avg_ms},
         }
+        # the secondary bound, HBM, from the measured bytes of the same kernel
+        tr = out["roofline"]["traffic"]
+        if tr and k0_avg_ms > 0:
+            gbs = tr / (k0_avg_ms * 1e-3) / 1e9
+            out["roofline"]["secondary"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s",
+                                            "frac": gbs / 8000.0}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, sqrt_spp, depth, budget_rows=H)
         print(json.dumps(out), flush=True)
