@@ -1,0 +1,46 @@
+"""bench.py's one-line JSON contract, on the GPU box: a short N = 1 run, and the one-GPU rehearsal of a
+rank of an N = 2 run (same code path as under torch.distributed.run, the collective left out)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(args, env_extra=None):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                       timeout=170, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_the_contract_fields():
+    d = run_bench(["--steps", "6", "--warmup", "2", "--no-cpu-baseline"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert (d["n_gpus"], d["steps"], d["warmup"], d["unit"], d["scaling"], d["dtype"]) == (1, 6, 2, "Mrays/s", "weak", "f32")
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True
+    assert "workload" in d["config"] and "1920x1080" in d["config"]["workload"]
+    assert d["config"]["rays_per_step"] == 57693197          # config 2's ray count, equal to the reference's
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert 0.05 < r["frac"] < 0.5 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert d["value"] > 2e4 and abs(d["value"] - d["config"]["rays_per_step"] / d["ms_per_step"] / 1e3) < 1e-3 * d["value"]
+
+
+@pytest.mark.parametrize("gather", ["side", "same"])
+def test_rank_of_a_two_gpu_run_rehearsed_on_one_gpu(gather):
+    d = run_bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--gather-stream", gather],
+                  {"RT_BENCH_REHEARSE_WORLD": "2", "RT_BENCH_REHEARSE_RANK": "1"})
+    assert d["n_gpus"] == 2 and "REHEARSAL" in d["data"]
+    assert d["value"] > 1e4
