@@ -258,6 +258,20 @@ __device__ __forceinline__ float acos_screen(float x)
     return x < 0.0f ? 3.14159265358979f - r : r;
 }
 
+/* The same with Abramowitz & Stegun 4.4.45 (cubic, |error| <= 5e-5): enough for the four edges of a
+ * quad - 4 * (5e-5 + 2.2e-5 cosine error at |c| <= 0.9985) + float summation < 3e-4, inside the 5e-4
+ * margin of the screening verdict (quad_screen) - and four multiply-adds shorter per edge. */
+__device__ __forceinline__ float acos_screen_quad(float x)
+{
+    const float ax = fabsf(x);
+    float p = -0.0187293f;
+    p = __builtin_fmaf(p, ax, 0.0742610f);
+    p = __builtin_fmaf(p, ax, -0.2121144f);
+    p = __builtin_fmaf(p, ax, 1.5707288f);
+    const float r = __builtin_amdgcn_sqrtf(1.0f - ax) * p;
+    return x < 0.0f ? 3.14159265358979f - r : r;
+}
+
 /*
  * Inside test of ray_intersect_polygon (ray.c:128-176): accept iff
  *     sum_i acos(costheta(v_i - pt, v_{i+1} - pt)) + .001 > 2*pi      (sum in double).
@@ -361,7 +375,8 @@ __device__ __forceinline__ int quad_screen(const Quad &q)
         c[i] = (dot3(q.ax[i], q.ay[i], q.az[i], q.ax[j], q.ay[j], q.az[j]) * r[i]) * r[j];
     }
     const float cmax = fmaxf(fmaxf(fabsf(c[0]), fabsf(c[1])), fmaxf(fabsf(c[2]), fabsf(c[3])));
-    const float total = (acos_screen(c[0]) + acos_screen(c[1])) + (acos_screen(c[2]) + acos_screen(c[3]));
+    const float total = (acos_screen_quad(c[0]) + acos_screen_quad(c[1])) +
+                        (acos_screen_quad(c[2]) + acos_screen_quad(c[3]));
     const float T = 6.2831853071795864769f - 0.001f;
     if (!(cmax <= 0.9985f))
         return 0;
@@ -867,6 +882,11 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
                                                 sobj, tl);
         if (hit && sobj == RT_NONE)
             visible |= 1u << (l & 31u);
+        if (n_lights == 1u) { /* one light: its direction waits in LDS for pass B (rows 7-9 are free until
+                                 the child searches) instead of being rebuilt there */
+            float *const keep = lds_park + threadIdx.x;
+            keep[7 * RT_BLOCK] = sh.dx; keep[8 * RT_BLOCK] = sh.dy; keep[9 * RT_BLOCK] = sh.dz;
+        }
         if ((l & 31u) == 31u && l + 1u < n_lights) {
             lds_vis[(l >> 5) * RT_BLOCK + threadIdx.x] = visible; /* own slot: no barrier needed */
             visible = 0;
@@ -902,9 +922,17 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
                 m &= m - 1u;
                 const float4 lp = tab[2u * l];
                 const float4 lc = tab[2u * l + 1u];
-                float sx = lp.x - px, sy = lp.y - py, sz = lp.z - pz;
-                const float inv = recip_rn(mag3(sx, sy, sz));
-                sx = sx * inv; sy = sy * inv; sz = sz * inv;
+                float sx, sy, sz;
+                if (n_lights == 1u) { /* parked by pass A: the same expressions, hence the same values */
+                    uint32_t t = threadIdx.x;
+                    asm volatile("" : "+v"(t));
+                    const float *back = lds_park + t;
+                    sx = back[7 * RT_BLOCK]; sy = back[8 * RT_BLOCK]; sz = back[9 * RT_BLOCK];
+                } else {
+                    sx = lp.x - px; sy = lp.y - py; sz = lp.z - pz;
+                    const float inv = recip_rn(mag3(sx, sy, sz));
+                    sx = sx * inv; sy = sy * inv; sz = sz * inv;
+                }
                 const float t = dot3(sx, sy, sz, Nx, Ny, Nz);
                 if (!(t <= 0.0f)) {
                     tl.lit();
