@@ -6,6 +6,7 @@
 #include "rt_device.h"
 #include "rt_hip.h"
 
+#include <cmath>
 #include <mutex>
 #include <stdarg.h>
 #include <stdio.h>
@@ -560,6 +561,115 @@ void rt_hip_ctx_set_batch_samples(rt_hip_ctx *c, uint64_t max_samples)
         c->batch_samples = max_samples;
 }
 
+namespace {
+/*
+ * Data of the kernels' first polygon screening stage (rt_kernels.hip, edge_screen): for a planar convex
+ * polygon, per edge i the unit in-plane inward normal m_i and offset k_i (g_i = m_i.p + k_i = signed
+ * distance from the edge's line), a "deep inside" threshold hin_i and one "far outside" threshold hout,
+ * stored as the single equation G_i = (g_i - hin_i) / (hin_i + hout): inside iff min G >= 0, outside iff
+ * min G <= -1.
+ * With L_i the edge length and a_i, b_i the distances from p to the edge's ends,
+ * sin(theta_i) = L_i g_i / (a_i b_i), and inside the polygon a_i b_i <= ((a_i + b_i)/2)^2 <= P_i, the
+ * largest such value at a vertex (a + b is convex).  The reference's float cosines (vec4_costheta:
+ * three products, two sums, two rounded square roots, a product, a quotient, on correctly rounded
+ * differences) are within 8e-7 of the exact ones, so its angle sum is within nv * 8e-7 / s_min of 2*pi
+ * when every sin(theta_i) >= s_min; s_min = nv * 1e-3 keeps that below 8e-4 of the .001 slack of
+ * ray.c:168.  Outside at distance >= h the exact sum is <= 2*pi - 4*asin(h / (h + D)), D the diameter
+ * (the polygon lies in a half-plane at distance h and within h + D), while a cosine at +-1 can move
+ * one angle by up to sqrt(2 * 8e-7) = 1.3e-3: hout asks for 4*asin(..) >= 1.3e-3 + nv * 1.3e-3.  Both get
+ * 10 % on top and the float evaluation error of g.  Anything not planar and convex gets infinite
+ * thresholds (never screened).
+ */
+void edge_screen_data(const rt_polygon &pg, std::vector<float4> &edges)
+{
+    const uint32_t nv = pg.nVerticies;
+    const size_t base = edges.size();
+    edges.resize(base + nv, make_float4(0.f, 0.f, 0.f, -0.5f));
+    if (nv < 3)
+        return;
+    auto V = [&](uint32_t i, double out[3]) {
+        out[0] = pg.vertex[i % nv].x; out[1] = pg.vertex[i % nv].y; out[2] = pg.vertex[i % nv].z;
+    };
+    double n[3] = {pg.plane.A, pg.plane.B, pg.plane.C};
+    const double nl = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    if (!(nl > 0.0))
+        return;
+    for (double &x : n)
+        x /= nl;
+    double D = 0.0, maxc = 0.0, cen[3] = {0, 0, 0}, v0[3];
+    V(0, v0);
+    for (uint32_t i = 0; i < nv; ++i) {
+        double a[3];
+        V(i, a);
+        for (int k = 0; k < 3; ++k) {
+            cen[k] += a[k] / nv;
+            maxc = fmax(maxc, fabs(a[k]));
+        }
+        for (uint32_t j = i + 1; j < nv; ++j) {
+            double b[3];
+            V(j, b);
+            D = fmax(D, sqrt((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2])));
+        }
+    }
+    if (!(D > 0.0) || !std::isfinite(D))
+        return;
+    /* the reference's plane is n.p + F = 0 with F forced >= 0 (geometry.c:29-32): planar means every
+     * vertex on the plane through v0 with that normal, AND that plane being the reference's */
+    for (uint32_t i = 0; i < nv; ++i) {
+        double a[3];
+        V(i, a);
+        const double d0 = n[0] * (a[0] - v0[0]) + n[1] * (a[1] - v0[1]) + n[2] * (a[2] - v0[2]);
+        const double dp = (pg.plane.A * a[0] + pg.plane.B * a[1] + pg.plane.C * a[2] + pg.plane.F) / nl;
+        if (fabs(d0) > 1e-6 * D || fabs(dp) > 1e-5 * (D + maxc))
+            return;
+    }
+    std::vector<double> e(4 * (size_t)nv), h(nv);
+    const double s_min = nv * 1e-3, eps = 1e-5 * (maxc + D);
+    for (uint32_t i = 0; i < nv; ++i) {
+        double a[3], b[3];
+        V(i, a);
+        V(i + 1, b);
+        const double d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+        const double L = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        if (!(L > 1e-6 * D))
+            return;
+        double m[3] = {n[1] * d[2] - n[2] * d[1], n[2] * d[0] - n[0] * d[2], n[0] * d[1] - n[1] * d[0]};
+        const double ml = sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+        if (!(ml > 0.0))
+            return;
+        double sgn = (m[0] * (cen[0] - a[0]) + m[1] * (cen[1] - a[1]) + m[2] * (cen[2] - a[2])) >= 0.0 ? 1.0 : -1.0;
+        for (double &x : m)
+            x *= sgn / ml;
+        for (uint32_t j = 0; j < nv; ++j) { /* convex: every vertex on the inner side of every edge */
+            double c[3];
+            V(j, c);
+            if (m[0] * (c[0] - a[0]) + m[1] * (c[1] - a[1]) + m[2] * (c[2] - a[2]) < -1e-6 * D)
+                return;
+        }
+        e[4 * i + 0] = m[0]; e[4 * i + 1] = m[1]; e[4 * i + 2] = m[2];
+        e[4 * i + 3] = -(m[0] * a[0] + m[1] * a[1] + m[2] * a[2]);
+        double P = 0.0; /* bound of a*b inside the polygon */
+        for (uint32_t j = 0; j < nv; ++j) {
+            double c[3];
+            V(j, c);
+            const double da = sqrt((c[0] - a[0]) * (c[0] - a[0]) + (c[1] - a[1]) * (c[1] - a[1]) + (c[2] - a[2]) * (c[2] - a[2]));
+            const double db = sqrt((c[0] - b[0]) * (c[0] - b[0]) + (c[1] - b[1]) * (c[1] - b[1]) + (c[2] - b[2]) * (c[2] - b[2]));
+            P = fmax(P, 0.25 * (da + db) * (da + db));
+        }
+        h[i] = 1.1 * s_min * P / L + eps;
+    }
+    const double q = (1.3e-3 + nv * 1.3e-3) / 4.0;
+    if (!(q < 0.5))
+        return; /* hundreds of vertices: no useful outside threshold */
+    const double hout = 1.1 * D * sin(q) / (1.0 - sin(q)) + eps;
+    for (uint32_t i = 0; i < nv; ++i) {
+        const double inv = 1.0 / (h[i] + hout);
+        edges[base + i] = make_float4((float)(e[4 * i + 0] * inv), (float)(e[4 * i + 1] * inv), (float)(e[4 * i + 2] * inv),
+                                      (float)((e[4 * i + 3] - h[i]) * inv));
+    }
+}
+} // namespace
+
 int rt_hip_scene_upload(rt_hip_ctx *c, const rt_scene *sc)
 {
     if (!c || !sc || (sc->nObjects && !sc->objects) || (sc->nLights && !sc->lights)) {
@@ -575,7 +685,7 @@ int rt_hip_scene_upload(rt_hip_ctx *c, const rt_scene *sc)
     }
 
     const uint32_t nObj = sc->nObjects, nL = sc->nLights;
-    std::vector<float4> sph, planes, infos, verts;
+    std::vector<float4> sph, planes, infos, verts, edges;
     std::vector<uint32_t> sph_obj;
     std::vector<float4> tab((size_t)2 * nL + (size_t)RT_OBJ_FIELDS * nObj);
     float4 *orec = tab.data() + (size_t)2 * nL;
@@ -610,6 +720,7 @@ int rt_hip_scene_upload(rt_hip_ctx *c, const rt_scene *sc)
             info.z = __builtin_bit_cast(float, i);
             info.w = 0.f;
             infos.push_back(info);
+            edge_screen_data(pg, edges);
             for (uint32_t v = 0; v < pg.nVerticies; ++v)
                 verts.push_back(make_float4(pg.vertex[v].x, pg.vertex[v].y, pg.vertex[v].z, pg.vertex[v].w));
             g = make_float4(pg.plane.A, pg.plane.B, pg.plane.C, 0.f);
@@ -619,7 +730,7 @@ int rt_hip_scene_upload(rt_hip_ctx *c, const rt_scene *sc)
         rec[RT_OBJ_SHAPE] = g;
     }
     const uint32_t nSph = (uint32_t)sph.size(), nPoly = (uint32_t)planes.size();
-    const size_t polySlots = 2 * (size_t)nPoly + verts.size();
+    const size_t polySlots = 2 * (size_t)nPoly + verts.size() + edges.size(); /* edges.size() == verts.size() */
     if (polySlots > RT_MAX_POLY_LDS) {
         set_err("polygon data needs %zu LDS slots, limit is %d", polySlots, RT_MAX_POLY_LDS);
         return RT_E_INVALID;
@@ -628,6 +739,7 @@ int rt_hip_scene_upload(rt_hip_ctx *c, const rt_scene *sc)
     poly.insert(poly.end(), planes.begin(), planes.end());
     poly.insert(poly.end(), infos.begin(), infos.end());
     poly.insert(poly.end(), verts.begin(), verts.end());
+    poly.insert(poly.end(), edges.begin(), edges.end());
     for (uint32_t l = 0; l < nL; ++l) {
         const rt_pointlight &L = sc->lights[l];
         tab[2 * l + 0] = make_float4(L.position.x, L.position.y, L.position.z, L.position.w);

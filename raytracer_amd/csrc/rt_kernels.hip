@@ -172,15 +172,39 @@ __device__ __forceinline__ float sphere_distance(float B, float det)
     return wOne > 0.0f ? wOne : 0.0f;
 }
 
-/* ray.c:128-176: sum of the angles pt subtends with consecutive vertices, in double; inside
- * iff sum + .001 > 2*pi.  (v_i - pt) and its length are shared by the two edges that use them;
- * the values are identical to the reference's recomputation.
- *
- * The cosines are formed in float exactly as the reference does (vec4_costheta).  The angles are
- * first taken with the fast float acosf; the float and double sums differ by < 4e-6, so only when
- * the float verdict is closer than 1e-4 to the threshold (a band a few micrometres wide around
- * the polygon's acceptance contour) is the sum redone with double acos, the reference's own
- * arithmetic (ray.c:142-145,160-163).  The decision therefore equals the reference's. */
+/*
+ * Inside test of ray_intersect_polygon (ray.c:128-176): accept iff
+ *     sum_i acos(costheta(v_i - pt, v_{i+1} - pt)) + .001 > 2*pi      (sum in double).
+ * Three stages, each deciding only what it can decide exactly like the reference:
+ *   1. edge_screen      signed distances from the polygon's edges (planar convex polygons): deep
+ *                       inside -> accept, far outside -> reject; ~36 instructions for a quad
+ *   2. float angle sum  the reference's own float cosines (vec4_costheta: IEEE sqrt and divide) with
+ *                       a polynomial acos and a float sum, which is within nv * 1e-6 of the
+ *                       reference's double sum: decides unless within 1e-4 (nv <= 25) of the threshold
+ *   3. rotation         the sign of the double sum minus the threshold, without acos (below)
+ * The instrumented build runs stages 2-3 for every test and counts stage-1 verdicts that contradict
+ * them (ST_POLY_SCREEN_MISMATCH must stay 0: asserted over 20 M tests of config 2 in the GPU suite).
+ */
+/* acos(x) for |x| <= 1 by Abramowitz & Stegun 4.4.46 (|error| <= 2e-8 before float rounding, ~1e-6
+ * after it): acos(x) = sqrt(1-x) * (a0 + a1 x + ... + a7 x^7) for x >= 0, pi - acos(-x) otherwise.
+ * The square root is the 1-ulp hardware approximation; |x| > 1 gives NaN, like acos. */
+__device__ __forceinline__ float acos_screen(float x)
+{
+    const float ax = fabsf(x);
+    float p = -0.0012624911f;
+    p = __builtin_fmaf(p, ax, 0.0066700901f);
+    p = __builtin_fmaf(p, ax, -0.0170881256f);
+    p = __builtin_fmaf(p, ax, 0.0308918810f);
+    p = __builtin_fmaf(p, ax, -0.0501743046f);
+    p = __builtin_fmaf(p, ax, 0.0889789874f);
+    p = __builtin_fmaf(p, ax, -0.2145988016f);
+    p = __builtin_fmaf(p, ax, 1.5707963050f);
+    const float r = __builtin_amdgcn_sqrtf(1.0f - ax) * p;
+    return x < 0.0f ? 3.14159265358979f - r : r;
+}
+
+/* sum of the angles pt subtends with consecutive vertices.  (v_i - pt) and its length are shared by the
+ * two edges that use them; the values are identical to the reference's recomputation. */
 template <typename T>
 __device__ __forceinline__ T polygon_angle_sum(const float4 *vtx, uint32_t nv, float px, float py,
                                                float pz)
@@ -198,14 +222,14 @@ __device__ __forceinline__ T polygon_angle_sum(const float4 *vtx, uint32_t nv, f
         if constexpr (sizeof(T) == 8)
             total += acos((double)c);
         else
-            total += acosf(c);
+            total += acos_screen(c);
         ax = bx; ay = by; az = bz; ma = mb;
     }
     const float c = div_rn(dot3(ax, ay, az, a0x, a0y, a0z), ma * m0);
     if constexpr (sizeof(T) == 8)
         total += acos((double)c);
     else
-        total += acosf(c);
+        total += acos_screen(c);
     return total;
 }
 
@@ -240,93 +264,13 @@ __device__ __forceinline__ void rot_by_cos(Rot &z, float c)
     z.im = im;
 }
 
-/* acos(x) for |x| <= 1 by Abramowitz & Stegun 4.4.46 (|error| <= 2e-8 before float rounding):
- * acos(x) = sqrt(1-x) * (a0 + a1 x + ... + a7 x^7) for x >= 0, pi - acos(-x) otherwise.  The
- * square root is the 1-ulp hardware approximation.  Used only by the screening pass below. */
-__device__ __forceinline__ float acos_screen(float x)
-{
-    const float ax = fabsf(x);
-    float p = -0.0012624911f;
-    p = __builtin_fmaf(p, ax, 0.0066700901f);
-    p = __builtin_fmaf(p, ax, -0.0170881256f);
-    p = __builtin_fmaf(p, ax, 0.0308918810f);
-    p = __builtin_fmaf(p, ax, -0.0501743046f);
-    p = __builtin_fmaf(p, ax, 0.0889789874f);
-    p = __builtin_fmaf(p, ax, -0.2145988016f);
-    p = __builtin_fmaf(p, ax, 1.5707963050f);
-    const float r = __builtin_amdgcn_sqrtf(1.0f - ax) * p;
-    return x < 0.0f ? 3.14159265358979f - r : r;
-}
-
-/* The same with Abramowitz & Stegun 4.4.45 (cubic, |error| <= 5e-5): enough for the four edges of a
- * quad - 4 * (5e-5 + 2.2e-5 cosine error at |c| <= 0.9985) + float summation < 3e-4, inside the 5e-4
- * margin of the screening verdict (quad_screen) - and four multiply-adds shorter per edge. */
-__device__ __forceinline__ float acos_screen_quad(float x)
-{
-    const float ax = fabsf(x);
-    float p = -0.0187293f;
-    p = __builtin_fmaf(p, ax, 0.0742610f);
-    p = __builtin_fmaf(p, ax, -0.2121144f);
-    p = __builtin_fmaf(p, ax, 1.5707288f);
-    const float r = __builtin_amdgcn_sqrtf(1.0f - ax) * p;
-    return x < 0.0f ? 3.14159265358979f - r : r;
-}
-
-/*
- * Inside test of ray_intersect_polygon (ray.c:128-176): accept iff
- *     sum_i acos(costheta(v_i - pt, v_{i+1} - pt)) + .001 > 2*pi      (sum in double).
- *
- * Screening pass.  The verdict only changes in a micrometre-wide band around the polygon's
- * acceptance contour, so most points can be classified from a cheap estimate of the sum:
- * cosines from the hardware reciprocal square root (no IEEE sqrt / divide), angles from
- * acos_screen.  With every |cosine| <= 0.9985 the estimate S' differs from the reference's sum S by
- * less than 4e-5 per edge (cosines agree to 1.2e-6, d(acos)/dx <= 18.3 there: 2.2e-5; acos_screen
- * 1e-6; float summation 1e-6), so for nv <= 12 edges
- *     S' > T + 5e-4  =>  S > T  (accept)      S' < T - 5e-4  =>  S < T  (reject),   T = 2*pi - .001.
- * Anything else - a cosine near +-1 (the point is almost collinear with an edge), a sum close to
- * T, NaNs, polygons with more than 12 vertices - takes the exact path: the reference's own
- * arithmetic (float cosines via IEEE sqrt and divide, acos, double sum), with float acosf first
- * and double acos when even that lands within 1e-4 of T.  Decisions are therefore identical to the
- * reference's; the instrumented build checks it (ST_POLY_SCREEN_MISMATCH must stay 0).
- */
-__device__ __forceinline__ int polygon_screen(const float4 *vtx, uint32_t nv, float px, float py, float pz)
-{
-    if (nv > 12u)
-        return 0;
-    const float4 v0 = vtx[0];
-    const float a0x = v0.x - px, a0y = v0.y - py, a0z = v0.z - pz;
-    const float r0 = __builtin_amdgcn_rsqf((a0x * a0x + a0y * a0y) + a0z * a0z);
-    float ax = a0x, ay = a0y, az = a0z, ra = r0;
-    float total = 0.0f, cmax = 0.0f;
-    for (uint32_t i = 1; i < nv; ++i) {
-        const float4 v = vtx[i];
-        const float bx = v.x - px, by = v.y - py, bz = v.z - pz;
-        const float rb = __builtin_amdgcn_rsqf((bx * bx + by * by) + bz * bz);
-        const float c = (dot3(ax, ay, az, bx, by, bz) * ra) * rb;
-        cmax = fmaxf(cmax, fabsf(c));
-        total += acos_screen(c);
-        ax = bx; ay = by; az = bz; ra = rb;
-    }
-    const float c = (dot3(ax, ay, az, a0x, a0y, a0z) * ra) * r0;
-    cmax = fmaxf(cmax, fabsf(c));
-    total += acos_screen(c);
-    const float T = 6.2831853071795864769f - 0.001f;
-    if (!(cmax <= 0.9985f)) /* also catches NaN cosines (fmaxf would drop them: tested below) */
-        return 0;
-    if (total > T + 5e-4f)
-        return 1;
-    if (total < T - 5e-4f)
-        return -1;
-    return 0; /* NaN totals land here too */
-}
-
 __device__ __forceinline__ bool polygon_inside_exact(const float4 *vtx, uint32_t nv, float px, float py,
                                                      float pz)
 {
     const float twopi = 6.2831853071795864769f;
     const float sf = polygon_angle_sum<float>(vtx, nv, px, py, pz);
     const float margin = (sf + 0.001f) - twopi;
-    if (fabsf(margin) > 1e-4f) /* NaN (a cosine outside [-1,1]) falls through to the double path */
+    if (fabsf(margin) > fmaxf(1e-4f, 4e-6f * (float)nv)) /* NaN (a cosine outside [-1,1]) falls through */
         return margin > 0.0f;
     /* The same float cosines again, folded into the rotation.  Both edge vectors are rebuilt per
      * edge (same expressions, same values) so that nothing but the rotation lives across the
@@ -363,30 +307,6 @@ __device__ __forceinline__ Quad quad_edges(const float4 *vtx, float px, float py
     return q;
 }
 
-__device__ __forceinline__ int quad_screen(const Quad &q)
-{
-    float r[4], c[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        r[i] = __builtin_amdgcn_rsqf((q.ax[i] * q.ax[i] + q.ay[i] * q.ay[i]) + q.az[i] * q.az[i]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int j = (i + 1) & 3;
-        c[i] = (dot3(q.ax[i], q.ay[i], q.az[i], q.ax[j], q.ay[j], q.az[j]) * r[i]) * r[j];
-    }
-    const float cmax = fmaxf(fmaxf(fabsf(c[0]), fabsf(c[1])), fmaxf(fabsf(c[2]), fabsf(c[3])));
-    const float total = (acos_screen_quad(c[0]) + acos_screen_quad(c[1])) +
-                        (acos_screen_quad(c[2]) + acos_screen_quad(c[3]));
-    const float T = 6.2831853071795864769f - 0.001f;
-    if (!(cmax <= 0.9985f))
-        return 0;
-    if (total > T + 5e-4f)
-        return 1;
-    if (total < T - 5e-4f)
-        return -1;
-    return 0; /* NaN cosines make the total NaN and land here */
-}
-
 __device__ __forceinline__ bool quad_inside_exact(const Quad &q)
 {
     float m[4], c[4];
@@ -399,7 +319,7 @@ __device__ __forceinline__ bool quad_inside_exact(const Quad &q)
         c[i] = div_rn(dot3(q.ax[i], q.ay[i], q.az[i], q.ax[j], q.ay[j], q.az[j]), m[i] * m[j]);
     }
     const float twopi = 6.2831853071795864769f;
-    const float sf = ((acosf(c[0]) + acosf(c[1])) + acosf(c[2])) + acosf(c[3]);
+    const float sf = ((acos_screen(c[0]) + acos_screen(c[1])) + acos_screen(c[2])) + acos_screen(c[3]);
     const float margin = (sf + 0.001f) - twopi;
     if (fabsf(margin) > 1e-4f)
         return margin > 0.0f;
@@ -410,44 +330,63 @@ __device__ __forceinline__ bool quad_inside_exact(const Quad &q)
     return z.im > 0.0;
 }
 
+/*
+ * First screening stage, for planar convex polygons (the host decides: rt_api.hip, edge_screen_data).
+ * With m_i the unit in-plane normal of edge i pointing inwards, g_i = m_i.p + k_i is the signed
+ * distance of the hit point from the edge's line; edg[i] holds the equation shifted and scaled,
+ * G_i = (g_i - hin_i) / (hin_i + hout), so that the two verdicts are min G >= 0 and min G <= -1:
+ *   every g_i >= hin_i                     => deep inside: the exact angle sum is 2*pi and the
+ *       reference's rounding (cosines within 8e-7, every sin(theta_i) = L_i g_i / (a_i b_i) >= nv*1e-3)
+ *       moves its sum by less than 8e-4: accepted there and here.
+ *   some  g_i <= -hout                      => at least hout away from the polygon: the exact sum is
+ *       below 2*pi - 4*asin(hout/(hout+D)), further below the acceptance threshold than the
+ *       reference's worst-case rounding (nv * 1.3e-3): rejected there and here.
+ * 30 instructions and four LDS reads for a quad against ~170 for the float angle sum, which now only sees the band
+ * around the edges.  Polygons that are not planar and convex carry the constant G = -0.5 (undecided).
+ */
+__device__ __forceinline__ int edge_screen(const float4 *edg, uint32_t nv, float px, float py, float pz)
+{
+    float gmin = 3.0e38f;
+    for (uint32_t i = 0; i < nv; ++i) {
+        const float4 e = edg[i];
+        gmin = fminf(gmin, dot3(e.x, e.y, e.z, px, py, pz) + e.w);
+    }
+    return gmin >= 0.0f ? 1 : (gmin <= -1.0f ? -1 : 0);
+}
+__device__ __forceinline__ int edge_screen_quad(const float4 *edg, float px, float py, float pz)
+{
+    const float4 e0 = edg[0], e1 = edg[1], e2 = edg[2], e3 = edg[3];
+    const float g0 = dot3(e0.x, e0.y, e0.z, px, py, pz) + e0.w, g1 = dot3(e1.x, e1.y, e1.z, px, py, pz) + e1.w;
+    const float g2 = dot3(e2.x, e2.y, e2.z, px, py, pz) + e2.w, g3 = dot3(e3.x, e3.y, e3.z, px, py, pz) + e3.w;
+    const float gmin = fminf(fminf(g0, g1), fminf(g2, g3));
+    return gmin >= 0.0f ? 1 : (gmin <= -1.0f ? -1 : 0);
+}
+
 /* QUAD: use the side-by-side quad evaluation (more registers, less latency).  The closest-hit
  * searches use it; the any-hit shadow search, which runs with all the shading state live, keeps
  * the register-light loops so that the kernel's register peak (and with it the number of waves a
  * SIMD can hold) is not set by a path that rarely runs. */
 template <bool STATS, bool QUAD>
-__device__ __forceinline__ bool polygon_inside(const float4 *vtx, uint32_t nv, float px, float py,
-                                               float pz, Tally<STATS> &tl)
+__device__ __forceinline__ bool polygon_inside(const float4 *vtx, const float4 *edg, uint32_t nv,
+                                               float px, float py, float pz, Tally<STATS> &tl)
 {
-#ifdef RT_ABL_NO_ANGLESUM /* development ablation: price of the angle sum (wrong pixels) */
+#ifdef RT_ABL_NO_ANGLESUM /* development ablation: price of the inside test (wrong pixels) */
     return px > -15.0f && px < 7.0f && pz > -100.0f && pz < 0.0f;
 #endif
-    if (QUAD && nv == 4u) {
-        const Quad q = quad_edges(vtx, px, py, pz);
-        const int s = quad_screen(q);
-        if constexpr (STATS) { /* instrumented build: always run the exact test and compare */
-            const bool e = quad_inside_exact(q);
-            if (s != 0 && (s > 0) != e)
-                tl.screen_mismatch();
-            if (s == 0)
-                tl.screen_unsure();
-            return e;
-        }
+    const bool quad = QUAD && nv == 4u;
+    const int s = quad ? edge_screen_quad(edg, px, py, pz) : edge_screen(edg, nv, px, py, pz);
+    if constexpr (!STATS) {
         if (s != 0)
             return s > 0;
-        return quad_inside_exact(q);
     }
-    const int s = polygon_screen(vtx, nv, px, py, pz);
+    const bool e = quad ? quad_inside_exact(quad_edges(vtx, px, py, pz)) : polygon_inside_exact(vtx, nv, px, py, pz);
     if constexpr (STATS) {
-        const bool e = polygon_inside_exact(vtx, nv, px, py, pz);
         if (s != 0 && (s > 0) != e)
             tl.screen_mismatch();
         if (s == 0)
             tl.screen_unsure();
-        return e;
     }
-    if (s != 0)
-        return s > 0;
-    return polygon_inside_exact(vtx, nv, px, py, pz);
+    return e;
 }
 
 /* powf(s, ke) of raytrace.c:371.  For the usual integral shininess (ke = 2, 20, ...) the power is a
@@ -645,7 +584,9 @@ __device__ __forceinline__ void intersect_all(const DevScene &S, const float4 *l
             if (!wins && !STATS)
                 continue;
             const float px = r.ox + r.dx * w, py = r.oy + r.dy * w, pz = r.oz + r.dz * w;
-            const bool inside = polygon_inside<STATS, !ANYHIT>(lds_poly + 2 * S.nPoly + __float_as_uint(info.x),
+            const float4 *const vtx = lds_poly + 2 * S.nPoly + __float_as_uint(info.x);
+            /* the edge equations follow the vertex pool, in the same order */
+            const bool inside = polygon_inside<STATS, !ANYHIT>(vtx, vtx + ((S.nPolySlots - 2u * S.nPoly) >> 1),
                                                       __float_as_uint(info.y), px, py, pz, tl);
             if (inside) {
                 tl.poly_hit();
@@ -1281,14 +1222,14 @@ __device__ __forceinline__ void flush_tally(uint64_t *st, Tally<STATS> &tl, bool
  * the sphere / polygon / light loops unroll, their branches and loop counters go away and the LDS
  * offsets fold (measured on the reference's scene: k_primary 0.348 -> 0.283 ms; the loops run 2, 1
  * and 1 times there, so their bookkeeping was a fifth of the kernel).  SHAPE 0 is any scene.
- *   SHAPE 1 = 2 spheres, 1 quad (6 polygon slots), 1 light, tables in LDS: the scene the
+ *   SHAPE 1 = 2 spheres, 1 quad (10 polygon slots), 1 light, tables in LDS: the scene the
  *             reference's parse_scene always returns (scene.c:86-258), i.e. every run of the reference.
  * rt_scene_shape() is the host-side match; the kernels overwrite their by-value copy of the counts.
  */
 template <int SHAPE> __device__ __forceinline__ void fix_shape(DevScene &) {}
 template <> __device__ __forceinline__ void fix_shape<1>(DevScene &S)
 {
-    S.nSph = 2u; S.nPoly = 1u; S.nPolySlots = 6u; S.nObj = 3u; S.nLights = 1u; S.tabSlots = 17u;
+    S.nSph = 2u; S.nPoly = 1u; S.nPolySlots = 10u; S.nObj = 3u; S.nLights = 1u; S.tabSlots = 17u;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -1674,7 +1615,7 @@ int rt_scene_shape(const DevScene &S)
     static const bool off = getenv("RT_HIP_NO_SHAPES") != nullptr; /* development: generic kernels only */
     if (off)
         return 0;
-    if (S.nSph == 2u && S.nPoly == 1u && S.nPolySlots == 6u && S.nObj == 3u && S.nLights == 1u &&
+    if (S.nSph == 2u && S.nPoly == 1u && S.nPolySlots == 10u && S.nObj == 3u && S.nLights == 1u &&
         S.tabSlots == 17u && S.tabInLds)
         return 1;
     return 0;
