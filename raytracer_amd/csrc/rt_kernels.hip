@@ -341,23 +341,28 @@ __device__ __forceinline__ bool quad_inside_exact(const Quad &q)
  *   some  g_i <= -hout                      => at least hout away from the polygon: the exact sum is
  *       below 2*pi - 4*asin(hout/(hout+D)), further below the acceptance threshold than the
  *       reference's worst-case rounding (nv * 1.3e-3): rejected there and here.
- * 30 instructions and four LDS reads for a quad against ~170 for the float angle sum, which now only sees the band
+ * 18 instructions and four LDS reads for a quad against ~170 for the float angle sum, which now only sees the band
  * around the edges.  Polygons that are not planar and convex carry the constant G = -0.5 (undecided).
  */
+/* (not one of the reference's operations: fused multiply-adds are fine here, and three instead of six) */
+__device__ __forceinline__ float edge_value(const float4 e, float px, float py, float pz)
+{
+    return __builtin_fmaf(e.x, px, __builtin_fmaf(e.y, py, __builtin_fmaf(e.z, pz, e.w)));
+}
 __device__ __forceinline__ int edge_screen(const float4 *edg, uint32_t nv, float px, float py, float pz)
 {
     float gmin = 3.0e38f;
     for (uint32_t i = 0; i < nv; ++i) {
         const float4 e = edg[i];
-        gmin = fminf(gmin, dot3(e.x, e.y, e.z, px, py, pz) + e.w);
+        gmin = fminf(gmin, edge_value(e, px, py, pz));
     }
     return gmin >= 0.0f ? 1 : (gmin <= -1.0f ? -1 : 0);
 }
 __device__ __forceinline__ int edge_screen_quad(const float4 *edg, float px, float py, float pz)
 {
     const float4 e0 = edg[0], e1 = edg[1], e2 = edg[2], e3 = edg[3];
-    const float g0 = dot3(e0.x, e0.y, e0.z, px, py, pz) + e0.w, g1 = dot3(e1.x, e1.y, e1.z, px, py, pz) + e1.w;
-    const float g2 = dot3(e2.x, e2.y, e2.z, px, py, pz) + e2.w, g3 = dot3(e3.x, e3.y, e3.z, px, py, pz) + e3.w;
+    const float g0 = edge_value(e0, px, py, pz), g1 = edge_value(e1, px, py, pz);
+    const float g2 = edge_value(e2, px, py, pz), g3 = edge_value(e3, px, py, pz);
     const float gmin = fminf(fminf(g0, g1), fminf(g2, g3));
     return gmin >= 0.0f ? 1 : (gmin <= -1.0f ? -1 : 0);
 }
@@ -379,6 +384,10 @@ __device__ __forceinline__ bool polygon_inside(const float4 *vtx, const float4 *
         if (s != 0)
             return s > 0;
     }
+#ifdef RT_ABL_NO_BAND /* development ablation: price of stages 2-3 (wrong pixels along polygon edges) */
+    if (!STATS)
+        return false;
+#endif
     const bool e = quad ? quad_inside_exact(quad_edges(vtx, px, py, pz)) : polygon_inside_exact(vtx, nv, px, py, pz);
     if constexpr (STATS) {
         if (s != 0 && (s > 0) != e)
