@@ -134,7 +134,7 @@ struct DevWork {
 #define RT_SHARDS      64
 #define RT_LINE_WORDS  32
 enum {
-    CNT_OVERFLOW = 0,              /* [RT_MAX_LEVELS] */
+    CNT_OVERFLOW = 0,              /* word 0: the batch overflowed somewhere (the other RT_MAX_LEVELS - 1 words are spare) */
     CNT_STATS = RT_MAX_LEVELS,
     CNT_STATS_STRIDE = 64,
     CNT_LEVELS = CNT_STATS + RT_SHARDS * CNT_STATS_STRIDE,

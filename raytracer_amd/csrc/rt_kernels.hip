@@ -684,14 +684,14 @@ __device__ __forceinline__ unsigned long long *level_line(uint32_t *counters, ui
     return (unsigned long long *)(counters + CNT_LEVELS + (level * RT_SHARDS + shard) * RT_LINE_WORDS);
 }
 
-/* did any kernel that processed a level < `levels` of this batch overflow?  Those kernels have
- * finished, so the answer is the same for every thread of the launch (block-uniform). */
-__device__ __forceinline__ bool overflowed_before(const uint32_t *counters, uint32_t levels)
+/* Did any kernel of this batch overflow a queue or a node range?  The batch is abandoned then (the
+ * host renders it again in smaller pieces) and every later kernel returns at once: its inputs hold
+ * unwritten slots.  The kernels that could have raised the flag have finished, so the answer is the
+ * same for every thread of the launch (block-uniform).  One word for the whole batch: the per-level
+ * words this replaced cost every thread of every fold launch 64 loads. */
+__device__ __forceinline__ bool overflowed_before(const uint32_t *counters)
 {
-    uint32_t f = 0;
-    for (uint32_t l = 0; l < levels; ++l)
-        f |= counters[CNT_OVERFLOW + l];
-    return f != 0;
+    return counters[CNT_OVERFLOW] != 0u;
 }
 
 /*
@@ -1076,7 +1076,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     /* tree node + queue slots for the children that hit: one reservation per wave */
     uint32_t *cnt = Wk.counters;
     uint32_t local, slot_r, slot_t;
-    wave_reserve(level_line(cnt, level, shard), hit_r, hit_t, node_room, Wk.capS, &cnt[CNT_OVERFLOW + level],
+    wave_reserve(level_line(cnt, level, shard), hit_r, hit_t, node_room, Wk.capS, &cnt[CNT_OVERFLOW],
                  local, slot_r, slot_t);
     pc.mark(5);
     if (local == RT_NONE) { /* overflow: the batch will be re-rendered in smaller pieces */
@@ -1324,7 +1324,7 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
             if (valid && !deferred && nroots != 0u) {
                 uint32_t local, no_r, no_t;
                 wave_reserve(level_line(Wk.counters, 0u, shard), false, false, Wk.capS, Wk.capS,
-                             &Wk.counters[CNT_OVERFLOW + 0u], local, no_r, no_t);
+                             &Wk.counters[CNT_OVERFLOW], local, no_r, no_t);
                 if (local != RT_NONE) {
                     node = node_base + local;
                     Wk.nodeA()[node] = make_float4(leaf[0], leaf[1], leaf[2], 0.0f);
@@ -1371,7 +1371,7 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_BOUNCE1 : RT_WPE)) v
     const uint32_t shard = blockIdx.x % RT_SHARDS;
     const uint32_t slice = blockIdx.x / RT_SHARDS, nslices = gridDim.x / RT_SHARDS;
     uint32_t *cnt = Wk.counters;
-    if (overflowed_before(cnt, level))
+    if (overflowed_before(cnt))
         return; /* the batch is being abandoned: its queues hold unwritten slots */
     const uint32_t n = min((uint32_t)(*level_line(cnt, level - 1, shard) >> 32), Wk.capS);
     if (slice * RT_BLOCK >= n)
@@ -1493,7 +1493,7 @@ __device__ __forceinline__ uint32_t fold_node(const DevWork &Wk, uint32_t i, flo
 __global__ __launch_bounds__(RT_BLOCK) void k_fold(DevWork Wk, uint32_t level)
 {
     uint32_t *cnt = Wk.counters;
-    if (overflowed_before(cnt, RT_MAX_LEVELS))
+    if (overflowed_before(cnt))
         return;
     const uint32_t shard = blockIdx.x % RT_SHARDS;
     const uint32_t slice = blockIdx.x / RT_SHARDS, nslices = gridDim.x / RT_SHARDS;
@@ -1519,7 +1519,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_fold(DevWork Wk, uint32_t level)
 __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DevCamera C, DevWork Wk, DevRows R,
                                                       uint32_t *argb, float *radiance)
 {
-    if (overflowed_before(Wk.counters, RT_MAX_LEVELS))
+    if (overflowed_before(Wk.counters))
         return; /* rows of an abandoned batch are rendered again by the host in smaller batches */
     const size_t npix = (size_t)R.ntiles * 8u * C.W;
     for (size_t p = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x; p < npix; p += (size_t)gridDim.x * RT_BLOCK) {
