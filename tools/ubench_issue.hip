@@ -54,6 +54,42 @@ KERNEL(k_v_jump2, "s_branch 1f\n 1:\n s_branch 2f\n 2:\n")
 KERNEL(k_v14, "v_fma_f32 %0, %0, %10, %11\n v_fma_f32 %1, %1, %10, %11\n v_fma_f32 %2, %2, %10, %11\n"
               "v_fma_f32 %3, %3, %10, %11\n")
 
+// packed f32: 5 v_pk_fma_f32 (= 10 fma) in place of 10 v_fma_f32, and the same for mul / add
+#define KERNEL_PK(NAME, OP)                                                                        \
+    __global__ __launch_bounds__(256) void NAME(float *out, int iters, float a, float b)           \
+    {                                                                                              \
+        typedef float f2 __attribute__((ext_vector_type(2)));                                      \
+        f2 r0 = {(float)threadIdx.x, 1.f}, r1 = r0 + 1.f, r2 = r0 + 2.f, r3 = r0 + 3.f, r4 = r0 + 4.f; \
+        f2 ka = {a, a}, kb = {b, b};                                                               \
+        for (int i = 0; i < iters; ++i) {                                                          \
+            asm volatile(REP16(OP " %0, %0, %5, %6\n" OP " %1, %1, %5, %6\n" OP " %2, %2, %5, %6\n" \
+                               OP " %3, %3, %5, %6\n" OP " %4, %4, %5, %6\n")                      \
+                         : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4)                        \
+                         : "v"(ka), "v"(kb));                                                      \
+        }                                                                                          \
+        f2 s = r0 + r1 + r2 + r3 + r4;                                                             \
+        out[blockIdx.x * 256 + threadIdx.x] = s.x + s.y;                                           \
+    }
+KERNEL_PK(k_pkfma5, "v_pk_fma_f32")
+#define KERNEL_PK2(NAME, OP)                                                                       \
+    __global__ __launch_bounds__(256) void NAME(float *out, int iters, float a, float b)           \
+    {                                                                                              \
+        typedef float f2 __attribute__((ext_vector_type(2)));                                      \
+        f2 r0 = {(float)threadIdx.x, 1.f}, r1 = r0 + 1.f, r2 = r0 + 2.f, r3 = r0 + 3.f, r4 = r0 + 4.f; \
+        f2 ka = {a, a};                                                                            \
+        for (int i = 0; i < iters; ++i) {                                                          \
+            asm volatile(REP16(OP " %0, %0, %5\n" OP " %1, %1, %5\n" OP " %2, %2, %5\n"            \
+                               OP " %3, %3, %5\n" OP " %4, %4, %5\n")                              \
+                         : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4)                        \
+                         : "v"(ka));                                                               \
+        }                                                                                          \
+        f2 s = r0 + r1 + r2 + r3 + r4;                                                             \
+        out[blockIdx.x * 256 + threadIdx.x] = s.x + s.y + b;                                       \
+    }
+KERNEL_PK2(k_pkmul5, "v_pk_mul_f32")
+KERNEL_PK2(k_pkadd5, "v_pk_add_f32")
+KERNEL(k_mul10, "")
+
 typedef void (*kern_t)(float *, int, float, float);
 
 int main(int argc, char **argv)
@@ -67,6 +103,8 @@ int main(int argc, char **argv)
         {"+4 s_nop 0", k_v_nop4, 4}, {"+4 s_add_i32", k_v_salu32, 4}, {"+2 x (saveexec, cbranch_execz, or exec)", k_v_if2, 6},
         {"+2 x (saveexec, or exec)", k_v_exec2, 4}, {"+2 v_cmp -> sgpr, 1 s_and_b64", k_v_cmp2, 3},
         {"+2 x (v_cmp vcc, v_cndmask)", k_v_sel2, 4}, {"+2 s_branch (taken)", k_v_jump2, 2}, {"+4 v_fma", k_v14, 4},
+        {"5 v_pk_fma_f32 INSTEAD of the 10 v_fma", k_pkfma5, 0}, {"5 v_pk_mul_f32 instead", k_pkmul5, 0},
+        {"5 v_pk_add_f32 instead", k_pkadd5, 0},
     };
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
