@@ -277,6 +277,13 @@ const char *rt_hip_version(void);
 int  rt_hip_selftest_arith(const float *d_a, const float *d_b, const float *d_c, uint32_t n,
                            float *d_out, double *d_out64, void *stream);
 
+/* Diagnostic (no counterpart in the reference): for n rays (DEVICE array, 7 floats each: origin,
+ * direction, magnitude) the sphere search of the uploaded big scene twice - through the grid the
+ * kernels walk, and as the reference's loop over every sphere (raytrace.c:188-272; filtered != 0:
+ * the _excl variant, 0 < d < magnitude).  d_out (DEVICE, 4 uint32 per ray) = object and distance bits
+ * from the grid, object and distance bits from the loop; they must be equal.  Blocking. */
+int  rt_hip_selftest_grid(rt_hip_ctx *ctx, const float *d_rays, uint32_t n, int filtered, uint32_t *d_out);
+
 /* ---- host-side scene helpers (reference scene.c / geometry.c equivalents) ---------- */
 
 /* poly_plane -- geometry.c:14-34 (normal from the first three vertices, F forced >= 0). */

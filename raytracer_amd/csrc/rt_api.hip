@@ -476,6 +476,25 @@ int rt_hip_selftest_arith(const float *d_a, const float *d_b, const float *d_c, 
     return 0;
 }
 
+int rt_hip_selftest_grid(rt_hip_ctx *c, const float *d_rays, uint32_t n, int filtered, uint32_t *d_out)
+{
+    if (!c || !c->have_scene || (n && (!d_rays || !d_out))) {
+        set_err("null argument or no scene");
+        return RT_E_INVALID;
+    }
+    if (!c->S.grid) {
+        set_err("the scene has no grid (%u spheres; grids are built above %d)", c->S.nSph, RT_TILE_SPHERES);
+        return RT_E_INVALID;
+    }
+    int rc = ctx_set_device(c);
+    if (rc)
+        return rc;
+    rt_launch_selftest_grid(c->S, d_rays, n, filtered != 0, d_out, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
 int rt_hip_ctx_create(rt_hip_ctx **out, int device, uint64_t max_queue_rays)
 {
     if (!out) {
@@ -670,6 +689,103 @@ void edge_screen_data(const rt_polygon &pg, std::vector<float4> &edges)
 }
 } // namespace
 
+namespace {
+/* Uniform grid over the spheres (GridHeader in rt_device.h): about two spheres per cell, at most 128
+ * cells per axis; a sphere goes into every cell its grown bounding box overlaps.
+ * Returns the words GridHeader | cellStart[cells + 1] | items. */
+void build_grid(const std::vector<float4> &sph, const rt_scene *sc, const std::vector<uint32_t> &sph_obj,
+                std::vector<uint32_t> &words)
+{
+    const size_t n = sph.size();
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    std::vector<double> rad(n);
+    for (size_t k = 0; k < n; ++k) {
+        rad[k] = fabs((double)sc->objects[sph_obj[k]].sphr_obj.radius);
+        const double c[3] = {sph[k].x, sph[k].y, sph[k].z};
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = fmin(lo[a], c[a] - rad[k]);
+            hi[a] = fmax(hi[a], c[a] + rad[k]);
+        }
+    }
+    double ext[3], vol = 1.0;
+    for (int a = 0; a < 3; ++a) {
+        const double pad = 1e-3 * (hi[a] - lo[a]) + 1e-4;
+        lo[a] -= pad;
+        hi[a] += pad;
+        ext[a] = hi[a] - lo[a];
+        vol *= ext[a];
+    }
+    const double cell = cbrt(vol * 2.0 / (double)n);
+    GridHeader G;
+    size_t cells = 1;
+    for (int a = 0; a < 3; ++a) {
+        long dm = lround(ext[a] / cell);
+        dm = dm < 1 ? 1 : (dm > 128 ? 128 : dm);
+        G.dim[a] = (uint32_t)dm;
+        G.gmin[a] = (float)lo[a];
+        G.gmax[a] = (float)hi[a];
+        G.h[a] = (float)(ext[a] / (double)dm);
+        G.inv_h[a] = (float)((double)dm / ext[a]);
+        cells *= (size_t)dm;
+    }
+    G.words = (uint32_t)(sizeof(GridHeader) / sizeof(uint32_t));
+    /* rays whose origin is within 1.5 box diagonals of the box centre are at most `reach` = 2 diagonals
+     * from any sphere: what the reference's test accepts beyond geometry at that reach (GridHeader) */
+    const double diag = sqrt(ext[0] * ext[0] + ext[1] * ext[1] + ext[2] * ext[2]);
+    const double reach = 2.0 * diag, extra2 = 2.0 * (double)RT_GRID_KAPPA * reach * reach;
+    for (int a = 0; a < 3; ++a)
+        G.centre[a] = (float)(0.5 * (lo[a] + hi[a]));
+    G.origin_reach2 = (float)(1.5 * diag * 1.5 * diag);
+    auto range = [&](size_t k, int a, long &c0, long &c1) {
+        const double c = a == 0 ? sph[k].x : a == 1 ? sph[k].y : sph[k].z;
+        const double h = (double)G.h[a], grow = sqrt(rad[k] * rad[k] + extra2) + 0.01 * h;
+        c0 = (long)floor((c - grow - (double)G.gmin[a]) / h);
+        c1 = (long)floor((c + grow - (double)G.gmin[a]) / h);
+        c0 = c0 < 0 ? 0 : c0;
+        c1 = c1 >= (long)G.dim[a] ? (long)G.dim[a] - 1 : c1;
+    };
+    std::vector<uint32_t> count(cells + 1, 0);
+    for (int pass = 0; pass < 2; ++pass) {
+        std::vector<uint32_t> fill;
+        std::vector<uint32_t> *out = nullptr;
+        static thread_local std::vector<uint32_t> items;
+        if (pass == 1) {
+            uint32_t run = 0; /* counts -> starts */
+            for (size_t i = 0; i <= cells; ++i) {
+                const uint32_t cnt = count[i];
+                count[i] = run;
+                run += cnt;
+            }
+            items.assign(run, 0);
+            fill.assign(count.begin(), count.end());
+            out = &items;
+        }
+        for (size_t k = 0; k < n; ++k) { /* ascending k: a cell's list comes out sorted */
+            long x0, x1, y0, y1, z0, z1;
+            range(k, 0, x0, x1);
+            range(k, 1, y0, y1);
+            range(k, 2, z0, z1);
+            for (long z = z0; z <= z1; ++z)
+                for (long y = y0; y <= y1; ++y)
+                    for (long x = x0; x <= x1; ++x) {
+                        const size_t ci = ((size_t)z * G.dim[1] + (size_t)y) * G.dim[0] + (size_t)x;
+                        if (pass == 0)
+                            count[ci]++;
+                        else
+                            (*out)[fill[ci]++] = (uint32_t)k;
+                    }
+        }
+        if (pass == 1) {
+            words.assign(G.words + cells + 1 + items.size(), 0u);
+            memcpy(words.data(), &G, sizeof G);
+            memcpy(words.data() + G.words, count.data(), (cells + 1) * sizeof(uint32_t));
+            if (!items.empty())
+                memcpy(words.data() + G.words + cells + 1, items.data(), items.size() * sizeof(uint32_t));
+        }
+    }
+}
+} // namespace
+
 int rt_hip_scene_upload(rt_hip_ctx *c, const rt_scene *sc)
 {
     if (!c || !sc || (sc->nObjects && !sc->objects) || (sc->nLights && !sc->lights)) {
@@ -746,11 +862,16 @@ int rt_hip_scene_upload(rt_hip_ctx *c, const rt_scene *sc)
         tab[2 * l + 1] = make_float4(L.color.r, L.color.g, L.color.b, 0.f);
     }
 
+    std::vector<uint32_t> grid;
+    if (nSph > RT_TILE_SPHERES)
+        build_grid(sph, sc, sph_obj, grid);
+
     /* one blob, 256-B aligned arrays */
     struct Seg { const void *src; size_t bytes; size_t off; };
-    Seg segs[4] = {
+    Seg segs[5] = {
         {sph.data(), sph.size() * sizeof(float4), 0},   {sph_obj.data(), sph_obj.size() * sizeof(uint32_t), 0},
-        {poly.data(), poly.size() * sizeof(float4), 0}, {tab.data(), tab.size() * sizeof(float4), 0}};
+        {poly.data(), poly.size() * sizeof(float4), 0}, {tab.data(), tab.size() * sizeof(float4), 0},
+        {grid.data(), grid.size() * sizeof(uint32_t), 0}};
     size_t total = 0;
     for (Seg &s : segs) {
         s.off = total;
@@ -780,6 +901,7 @@ int rt_hip_scene_upload(rt_hip_ctx *c, const rt_scene *sc)
     S.sph_obj = (const uint32_t *)(b + segs[1].off);
     S.poly = (const float4 *)(b + segs[2].off);
     S.tab = (const float4 *)(b + segs[3].off);
+    S.grid = grid.empty() ? nullptr : (const uint32_t *)(b + segs[4].off);
     S.nSph = nSph;
     S.nPoly = nPoly;
     S.nPolySlots = (uint32_t)polySlots;

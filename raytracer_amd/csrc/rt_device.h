@@ -12,7 +12,7 @@
 #define RT_MAX_LEVELS   64          /* supported recursion depth: 0 .. RT_MAX_LEVELS-2 */
 #define RT_NONE         0xFFFFFFFFu
 #define RT_LINK_NONE    0x1FFFFFFFu /* 29-bit "no parent / end of chain" */
-#define RT_TILE_SPHERES 2048        /* spheres per LDS tile (32 KiB)  */
+#define RT_TILE_SPHERES 2048        /* most spheres kept in LDS (32 KiB); scenes with more walk a grid */
 #define RT_MAX_POLY_LDS 1024        /* float4 slots for planes + info + vertices in LDS */
 #define RT_BLOCK        256
 /* per-thread parking area at the start of every trace kernel's LDS (row-major [word][thread],
@@ -48,11 +48,35 @@ struct DevScene {
                                  tab[2*nLights + 5*o + k]  = object o, RT_OBJ_* field k
                                  (one 80-byte record per object: a lane that shades object o
                                  touches one or two cache lines, not five arrays)            */
+    const uint32_t *grid;     /* scenes with more than RT_TILE_SPHERES spheres: GridHeader, then
+                                 cellStart[cells + 1], then the cells' sphere indices (ascending
+                                 within a cell); nullptr otherwise                              */
     uint32_t nSph, nPoly, nPolySlots, nObj, nLights;
     uint32_t tabSlots;        /* 2*nLights + 5*nObj                                          */
     uint32_t tabInLds;        /* the tables are small enough to be staged in LDS per block   */
     float bg[3];
     float ambient[3];
+};
+
+/* Uniform grid over the spheres of a big scene (built by rt_hip_scene_upload).  A sphere is listed in
+ * every cell its GROWN bounding box overlaps.  The growth covers what the reference's sphere test
+ * (ray.c:185-209: B*B - 4*C without the quadratic's leading coefficient) accepts beyond geometry: with
+ * a direction of squared length 1 +- kappa and float rounding, a sphere at distance <= reach whose
+ * centre is up to sqrt(r*r + 2*kappa*reach*reach) from the ray's line can still come out as a hit, and
+ * the line's point at the reported distance lies that close to the centre (rt_api.hip, build_grid).
+ * Rays outside those assumptions (direction not of unit length: the reference's refraction formula
+ * produces such rays; origin farther than `reach` allows) loop over all spheres instead. */
+#define RT_GRID_KAPPA 3.0e-6f /* bound of | |dir|^2 - 1 | + float rounding of the discriminant, per unit reach^2 */
+#define RT_GRID_UNIT  1.0e-6f /* a ray walks the grid only if | |dir|^2 - 1 | <= this */
+struct GridHeader {
+    float gmin[3];   /* lower corner                     */
+    float gmax[3];   /* upper corner                     */
+    float h[3];      /* cell size per axis               */
+    float inv_h[3];
+    uint32_t dim[3]; /* cells per axis                   */
+    uint32_t words;  /* size of this header in uint32_t  */
+    float centre[3]; /* of the box                       */
+    float origin_reach2; /* a ray walks the grid only if its origin is within sqrt(this) of the centre */
 };
 
 /* fields of an object record in DevScene::tab */
@@ -168,6 +192,8 @@ void rt_launch_fold(const DevWork &Wk, uint32_t level, uint32_t expect, hipStrea
 void rt_launch_resolve(const DevCamera &C, const DevWork &Wk, const DevRows &R, uint32_t *d_argb,
                        float *d_radiance, hipStream_t stream);
 size_t rt_scene_lds_bytes(const DevScene &S);
+void rt_launch_selftest_grid(const DevScene &S, const float *rays, uint32_t n, bool filtered, uint32_t *out,
+                             hipStream_t stream);
 int rt_scene_shape(const DevScene &S); /* 0 = generic kernels, else the specialisation (rt_kernels.hip) */
 void rt_launch_publish(uint32_t *counters, uint32_t *mirror, uint32_t words, hipStream_t stream);
 void rt_launch_deinterleave(const uint32_t *gathered, uint32_t *frame, uint32_t width, uint32_t height,

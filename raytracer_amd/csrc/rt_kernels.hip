@@ -427,13 +427,172 @@ __device__ __forceinline__ float phong_pow(float s, float ke)
  * object indices (sph_obj), so that the closest-hit search never waits on a global load */
 __host__ __device__ __forceinline__ uint32_t sphere_slots(uint32_t nSph)
 {
-    return nSph > RT_TILE_SPHERES ? (uint32_t)RT_TILE_SPHERES : nSph + (nSph + 3u) / 4u;
+    return nSph > RT_TILE_SPHERES ? 0u : nSph + (nSph + 3u) / 4u; /* (big scenes walk a grid in HBM) */
 }
 
 __device__ __forceinline__ void block_copy(float4 *dst, const float4 *src, uint32_t n)
 {
     for (uint32_t i = threadIdx.x; i < n; i += RT_BLOCK)
         dst[i] = src[i];
+}
+
+/*
+ * Sphere search of a big scene (more than RT_TILE_SPHERES spheres): walk the cells of a uniform grid
+ * along the ray (3-D DDA) and test only the spheres listed there, instead of all of them - the same
+ * winner as the reference's loop over every sphere (smallest accepted distance, lowest index on a
+ * tie), because
+ *   - a sphere is listed in every cell its slightly grown bounding box overlaps, so every sphere the
+ *     ray's line touches is met in some visited cell (testing a sphere twice changes nothing);
+ *   - the unfiltered search (primary rays) walks the WHOLE line inside the grid, also behind the
+ *     origin: the reference gives distance 0 to a sphere whose centre is behind the ray but whose
+ *     line it crosses (ray.c:209-231), and such a sphere then wins;
+ *   - the walk stops early only when the best distance so far is smaller than the parameter at
+ *     which the ray leaves the current cell (no unvisited cell can hold a nearer crossing), or, for
+ *     shadow rays, at the first accepted hit.
+ * The grid lives in HBM (L2-resident: 16 384 spheres need ~0.6 MB); every lane walks its own cells.
+ */
+template <bool FILTERED, bool ANYHIT, bool STATS, bool EARLY, class Disc, class Cand>
+__device__ __forceinline__ void grid_walk(const DevScene &S, const Ray &r, bool &found, float &d,
+                                          Disc &discriminant, Cand &candidate, Tally<STATS> &tl,
+                                          uint32_t exc_sph)
+{
+    const GridHeader *G = (const GridHeader *)S.grid;
+    const uint32_t d0 = G->dim[0], d1 = G->dim[1], d2 = G->dim[2];
+    const uint32_t *cellStart = S.grid + G->words;
+    const uint32_t *items = cellStart + (d0 * d1 * d2 + 1u);
+    const float o[3] = {r.ox, r.oy, r.oz}, dir[3] = {r.dx, r.dy, r.dz};
+    float t0 = FILTERED ? 0.0f : -3.0e38f, t1 = FILTERED ? r.mag : 3.0e38f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { /* the part of the ray inside the grid's box */
+        if (dir[a] != 0.0f) {
+            const float inv = 1.0f / dir[a];
+            const float ta = (G->gmin[a] - o[a]) * inv, tb = (G->gmax[a] - o[a]) * inv;
+            t0 = fmaxf(t0, fminf(ta, tb));
+            t1 = fminf(t1, fmaxf(ta, tb));
+        } else if (o[a] < G->gmin[a] || o[a] > G->gmax[a]) {
+            return;
+        }
+    }
+    if (!(t0 <= t1))
+        return;
+    int c[3], step[3];
+    float tmax[3], tdel[3];
+    const uint32_t dim[3] = {d0, d1, d2};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float p = o[a] + dir[a] * t0;
+        int ci = (int)floorf((p - G->gmin[a]) * G->inv_h[a]);
+        ci = ci < 0 ? 0 : (ci >= (int)dim[a] ? (int)dim[a] - 1 : ci);
+        c[a] = ci;
+        if (dir[a] > 0.0f) {
+            step[a] = 1;
+            tmax[a] = (G->gmin[a] + (float)(ci + 1) * G->h[a] - o[a]) / dir[a];
+            tdel[a] = G->h[a] / dir[a];
+        } else if (dir[a] < 0.0f) {
+            step[a] = -1;
+            tmax[a] = (G->gmin[a] + (float)ci * G->h[a] - o[a]) / dir[a];
+            tdel[a] = -G->h[a] / dir[a];
+        } else {
+            step[a] = 0;
+            tmax[a] = 3.0e38f;
+            tdel[a] = 3.0e38f;
+        }
+    }
+    /* at most one cell per step along some axis: the count bounds the loop whatever the arithmetic does */
+    for (uint32_t left = d0 + d1 + d2 + 3u; left; --left) {
+        const uint32_t cell = ((uint32_t)c[2] * d1 + (uint32_t)c[1]) * d0 + (uint32_t)c[0];
+        const uint32_t beg = cellStart[cell], end = cellStart[cell + 1u];
+        for (uint32_t j = beg; j < end; ++j) {
+            const uint32_t k = items[j];
+            if (FILTERED && k == exc_sph)
+                continue;
+            tl.sph_test();
+            float B;
+            const float det = discriminant(S.sph[k], B);
+            if (!(det < 0.0f))
+                candidate(k, B, det, false);
+        }
+        const float texit = fminf(tmax[0], fminf(tmax[1], tmax[2]));
+        if (found && !STATS) {
+            if (ANYHIT)
+                break;
+            if (EARLY && texit > 0.0f && d < texit - (1e-5f + 1e-5f * texit))
+                break;
+        }
+        if (!(texit < t1))
+            break; /* the ray leaves the box (or ends) inside this cell */
+        const int a = (tmax[0] <= tmax[1]) ? ((tmax[0] <= tmax[2]) ? 0 : 2) : ((tmax[1] <= tmax[2]) ? 1 : 2);
+        /* (selects instead of run-time indexed arrays: those would live in scratch memory) */
+        const int nc = (a == 0 ? c[0] : a == 1 ? c[1] : c[2]) + (a == 0 ? step[0] : a == 1 ? step[1] : step[2]);
+        if (nc < 0 || nc >= (int)(a == 0 ? d0 : a == 1 ? d1 : d2))
+            break;
+        if (a == 0) { c[0] = nc; tmax[0] += tdel[0]; }
+        else if (a == 1) { c[1] = nc; tmax[1] += tdel[1]; }
+        else { c[2] = nc; tmax[2] += tdel[2]; }
+    }
+}
+
+/*
+ * The reference's loop over EVERY sphere, for the lanes whose ray cannot use the grid, done by the
+ * whole wave: the lanes take such rays one at a time, each lane tests every 64th sphere against the
+ * broadcast ray (coalesced loads), and a butterfly reduction picks the smallest accepted distance,
+ * the lowest index on a tie - the loop's winner (raytrace.c:188-272).  Must be reached by all 64 lanes.
+ */
+template <bool FILTERED, bool STATS>
+__device__ __forceinline__ void wave_loop_all(const DevScene &S, bool need, const Ray &r, uint32_t exc_sph,
+                                              bool &found, float &d, uint32_t &best_k, Tally<STATS> &tl)
+{
+    unsigned long long todo = __ballot(need);
+    const uint32_t lane = lane_id();
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const float ox = __shfl(r.ox, src, 64), oy = __shfl(r.oy, src, 64), oz = __shfl(r.oz, src, 64);
+        const float dx = __shfl(r.dx, src, 64), dy = __shfl(r.dy, src, 64), dz = __shfl(r.dz, src, 64);
+        const float mag = __shfl(r.mag, src, 64);
+        const uint32_t exc = __shfl(exc_sph, src, 64);
+        bool f = false;
+        float bw = 0.0f;
+        uint32_t bk = RT_NONE;
+        for (uint32_t k = lane; k < S.nSph; k += 64u) {
+            if (FILTERED && k == exc)
+                continue;
+            tl.sph_test();
+            const float4 s = S.sph[k];
+            const float ex = ox - s.x, ey = oy - s.y, ez = oz - s.z;
+            const float B = 2.0f * ((dx * ex + dy * ey) + dz * ez);
+            const float Cq = ((ex * ex + ey * ey) + ez * ez) - s.w;
+            const float det = (B * B) - (4.0f * Cq);
+            if (det < 0.0f)
+                continue;
+            tl.sph_hit();
+            if (FILTERED && !(B < 0.0f))
+                continue;
+            const float w = sphere_distance(B, det);
+            if (FILTERED && !(w < mag && w > 0.0f))
+                continue;
+            if (!f || w < bw) { /* ascending k within a lane: the first of equal distances stays */
+                bw = w;
+                bk = k;
+                f = true;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const bool of = __shfl_xor((int)f, off, 64) != 0;
+            const float ow = __shfl_xor(bw, off, 64);
+            const uint32_t ok = __shfl_xor(bk, off, 64);
+            if (of && (!f || ow < bw || (ow == bw && ok < bk))) {
+                f = true;
+                bw = ow;
+                bk = ok;
+            }
+        }
+        if ((int)lane == src) {
+            found = f;
+            d = bw;
+            best_k = bk;
+        }
+    }
 }
 
 /*
@@ -447,8 +606,8 @@ __device__ __forceinline__ void block_copy(float4 *dst, const float4 *src, uint3
  * lane stops at its first accepted hit.  STATS disables that early exit and counts every test
  * the reference would make.
  *
- * TILED: the sphere list does not fit one LDS tile; the tile loop contains block barriers, so
- * every thread of the block must call this function (inactive lanes pass active=false).
+ * TILED: more spheres than LDS holds (RT_TILE_SPHERES): the spheres are searched through a grid in
+ * HBM (grid_walk) instead of a loop over all of them.
  */
 template <bool TILED, bool FILTERED, bool ANYHIT, bool STATS, bool BIG, bool EYE = false>
 __device__ __forceinline__ void intersect_all(const DevScene &S, const float4 *lds_poly,
@@ -465,93 +624,107 @@ __device__ __forceinline__ void intersect_all(const DevScene &S, const float4 *l
     uint32_t best_k = RT_NONE; /* winning sphere-list index */
     bool found = false;
 
-    for (uint32_t t0 = 0; t0 < S.nSph; t0 += RT_TILE_SPHERES) {
-        const uint32_t cnt = min((uint32_t)RT_TILE_SPHERES, S.nSph - t0);
-        if (TILED) {
-            __syncthreads();
-            block_copy(lds_sph, S.sph + t0, cnt);
-            __syncthreads();
+    /* one sphere against this lane's ray: ray.c:185-195 up to the discriminant */
+    auto discriminant = [&](const float4 s, float &B) -> float {
+        if (EYE) { /* s = (ex, ey, ez, 4*Cq) */
+            B = 2.0f * ((r.dx * s.x + r.dy * s.y) + r.dz * s.z);
+            return (B * B) - s.w;
         }
-        if (active && !(ANYHIT && !STATS && found)) {
-            /* one sphere against this lane's ray: ray.c:185-195 up to the discriminant */
-            auto discriminant = [&](const float4 s, float &B) -> float {
-                if (EYE) { /* s = (ex, ey, ez, 4*Cq) */
-                    B = 2.0f * ((r.dx * s.x + r.dy * s.y) + r.dz * s.z);
-                    return (B * B) - s.w;
-                }
-                const float ex = r.ox - s.x, ey = r.oy - s.y, ez = r.oz - s.z;
-                B = 2.0f * ((r.dx * ex + r.dy * ey) + r.dz * ez);
-                const float Cq = ((ex * ex + ey * ey) + ez * ez) - s.w;
-                return (B * B) - (4.0f * Cq);
-            };
-            /* a sphere whose discriminant is not negative: ray.c:209-240 and the caller's filter */
-            auto candidate = [&](uint32_t k, float B, float det) {
-                tl.sph_hit();
-                if (FILTERED) {
-                    /* only 0 < w < magnitude can be accepted; w > 0 needs B < 0 */
-                    if (B < 0.0f) {
-                        const float w = sphere_distance(B, det);
-                        if (w < r.mag && w > 0.0f && (!found || w < d)) {
-                            d = w;
-                            best_k = k;
-                            found = true;
-                        }
-                    }
-                } else {
-                    const float w = sphere_distance(B, det);
-                    if (!found || w < d) {
-                        d = w;
-                        best_k = k;
-                        found = true;
-                    }
-                }
-            };
-            uint32_t j = 0;
-            if (BIG) {
-                /* Scenes with hundreds of spheres: RT_SPHERES_PER_TRIP spheres per trip.  The LDS reads are
-                 * in flight together and the loop's scalar bookkeeping is shared; with one sphere
-                 * per trip every test waited out its own LDS round trip at 2-3 waves per SIMD (the
-                 * sphere tile leaves room for no more).  Candidates are still taken in list order. */
-                constexpr uint32_t U = RT_SPHERES_PER_TRIP;
-                for (; j + U <= cnt; j += U) {
-                    float Bq[U], detq[U];
-                    float4 sq[U];
-#pragma unroll
-                    for (uint32_t u = 0; u < U; ++u)
-                        sq[u] = lds_sph[j + u];
-                    bool any = false;
-#pragma unroll
-                    for (uint32_t u = 0; u < U; ++u) {
-                        detq[u] = discriminant(sq[u], Bq[u]);
-                        if (FILTERED && (t0 + j + u) == exc_sph)
-                            detq[u] = -1.0f; /* the excluded sphere: never a candidate, never counted */
-                        else
-                            tl.sph_test();
-                        any = any || !(detq[u] < 0.0f);
-                    }
-                    if (any) {
-#pragma unroll
-                        for (uint32_t u = 0; u < U; ++u)
-                            if (!(detq[u] < 0.0f))
-                                candidate(t0 + j + u, Bq[u], detq[u]);
-                        if (ANYHIT && !STATS && found)
-                            break;
-                    }
+        const float ex = r.ox - s.x, ey = r.oy - s.y, ez = r.oz - s.z;
+        B = 2.0f * ((r.dx * ex + r.dy * ey) + r.dz * ez);
+        const float Cq = ((ex * ex + ey * ey) + ez * ez) - s.w;
+        return (B * B) - (4.0f * Cq);
+    };
+    /* a sphere whose discriminant is not negative: ray.c:209-240 and the caller's filter.  ORDERED:
+     * candidates arrive in list order (the reference's loop: the first of equal distances wins);
+     * otherwise (grid walk) ties go to the lower index explicitly. */
+    auto candidate = [&](uint32_t k, float B, float det, bool ordered) {
+        tl.sph_hit();
+        if (FILTERED) {
+            /* only 0 < w < magnitude can be accepted; w > 0 needs B < 0 */
+            if (B < 0.0f) {
+                const float w = sphere_distance(B, det);
+                if (w < r.mag && w > 0.0f && (!found || w < d || (!ordered && w == d && k < best_k))) {
+                    d = w;
+                    best_k = k;
+                    found = true;
                 }
             }
-            if (!(BIG && ANYHIT && !STATS && found)) {
-                for (; j < cnt; ++j) {
-                    const float4 s = EYE ? eye_terms[j] : lds_sph[j]; /* same address in all lanes: LDS broadcast */
-                    if (FILTERED && (t0 + j) == exc_sph)
-                        continue;
-                    tl.sph_test();
-                    float B;
-                    const float det = discriminant(s, B);
-                    if (!(det < 0.0f)) {
-                        candidate(t0 + j, B, det);
-                        if (ANYHIT && !STATS && found)
-                            break;
-                    }
+        } else {
+            const float w = sphere_distance(B, det);
+            if (!found || w < d || (!ordered && w == d && k < best_k)) {
+                d = w;
+                best_k = k;
+                found = true;
+            }
+        }
+    };
+    if (TILED) {
+        /* the grid is only exact for rays the reference's test treats (almost) geometrically: a
+         * direction of unit length (shorter ones are fine too: the test then accepts LESS than
+         * geometry, but the reported distance is off the sphere, so they walk without early exit) and
+         * an origin within the grid's reach (GridHeader).  The reference's refraction formula
+         * (raytrace.c:517-525) makes rays LONGER than unit when they leave a sphere with n < 1
+         * (|d|^2 = 1 + (1 - cos^2)(1/n^2 - n^2)): for those the reference's test accepts spheres in a
+         * cone around the ray, and they take the reference's own loop over every sphere. */
+        const GridHeader *G = (const GridHeader *)S.grid;
+        const float l2 = (r.dx * r.dx + r.dy * r.dy) + r.dz * r.dz;
+        const float qx = r.ox - G->centre[0], qy = r.oy - G->centre[1], qz = r.oz - G->centre[2];
+        const bool walk = active && (l2 - 1.0f <= RT_GRID_UNIT) && ((qx * qx + qy * qy) + qz * qz <= G->origin_reach2);
+        if (walk) {
+            if (l2 - 1.0f >= -RT_GRID_UNIT)
+                grid_walk<FILTERED, ANYHIT, STATS, true>(S, r, found, d, discriminant, candidate, tl, exc_sph);
+            else
+                grid_walk<FILTERED, ANYHIT, STATS, false>(S, r, found, d, discriminant, candidate, tl, exc_sph);
+        }
+        wave_loop_all<FILTERED, STATS>(S, active && !walk, r, exc_sph, found, d, best_k, tl);
+    } else if (active) {
+        const uint32_t cnt = S.nSph;
+        uint32_t j = 0;
+        if (BIG) {
+            /* Scenes with hundreds of spheres: RT_SPHERES_PER_TRIP spheres per trip.  The LDS reads are
+             * in flight together and the loop's scalar bookkeeping is shared; with one sphere
+             * per trip every test waited out its own LDS round trip at 2-3 waves per SIMD (the
+             * sphere tile leaves room for no more).  Candidates are still taken in list order. */
+            constexpr uint32_t U = RT_SPHERES_PER_TRIP;
+            for (; j + U <= cnt; j += U) {
+                float Bq[U], detq[U];
+                float4 sq[U];
+#pragma unroll
+                for (uint32_t u = 0; u < U; ++u)
+                    sq[u] = lds_sph[j + u];
+                bool any = false;
+#pragma unroll
+                for (uint32_t u = 0; u < U; ++u) {
+                    detq[u] = discriminant(sq[u], Bq[u]);
+                    if (FILTERED && (j + u) == exc_sph)
+                        detq[u] = -1.0f; /* the excluded sphere: never a candidate, never counted */
+                    else
+                        tl.sph_test();
+                    any = any || !(detq[u] < 0.0f);
+                }
+                if (any) {
+#pragma unroll
+                    for (uint32_t u = 0; u < U; ++u)
+                        if (!(detq[u] < 0.0f))
+                            candidate(j + u, Bq[u], detq[u], true);
+                    if (ANYHIT && !STATS && found)
+                        break;
+                }
+            }
+        }
+        if (!(BIG && ANYHIT && !STATS && found)) {
+            for (; j < cnt; ++j) {
+                const float4 s = EYE ? eye_terms[j] : lds_sph[j]; /* same address in all lanes: LDS broadcast */
+                if (FILTERED && j == exc_sph)
+                    continue;
+                tl.sph_test();
+                float B;
+                const float det = discriminant(s, B);
+                if (!(det < 0.0f)) {
+                    candidate(j, B, det, true);
+                    if (ANYHIT && !STATS && found)
+                        break;
                 }
             }
         }
@@ -1616,6 +1789,54 @@ __global__ __launch_bounds__(RT_BLOCK) void k_selftest_arith(const float *a, con
     out64[i] = sqrt_rn_f64_pos((double)x);
 }
 
+/* rt_hip_selftest_grid: for n rays (7 floats each: origin, direction, magnitude) the sphere search of a
+ * big scene twice - through the grid, and as the reference's loop over every sphere - so that a test
+ * can demand identical winners.  out[4*i..] = object, distance bits (grid), object, distance bits (loop). */
+template <bool FILTERED>
+__global__ __launch_bounds__(RT_BLOCK) void k_selftest_grid(DevScene S, const float *rays, uint32_t n, uint32_t *out)
+{
+    const uint32_t i0 = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const bool act = i0 < n; /* (no early return: the search needs whole waves) */
+    const uint32_t i = act ? i0 : n - 1u;
+    S.nPoly = 0u; /* spheres only */
+    Ray r;
+    r.ox = rays[7 * i + 0]; r.oy = rays[7 * i + 1]; r.oz = rays[7 * i + 2];
+    r.dx = rays[7 * i + 3]; r.dy = rays[7 * i + 4]; r.dz = rays[7 * i + 5];
+    r.mag = rays[7 * i + 6];
+    Tally<false> tl;
+    float dg = 0.0f;
+    uint32_t og = RT_NONE;
+    intersect_all<true, FILTERED, false, false, true>(S, nullptr, nullptr, act, r, RT_NONE, RT_NONE, dg, og, tl);
+    if (!act)
+        return;
+    bool found = false;
+    float d = 0.0f;
+    uint32_t best = RT_NONE;
+    for (uint32_t k = 0; k < S.nSph; ++k) { /* raytrace.c:188-272 over the sphere list */
+        const float4 s = S.sph[k];
+        const float ex = r.ox - s.x, ey = r.oy - s.y, ez = r.oz - s.z;
+        const float B = 2.0f * ((r.dx * ex + r.dy * ey) + r.dz * ez);
+        const float Cq = ((ex * ex + ey * ey) + ez * ez) - s.w;
+        const float det = (B * B) - (4.0f * Cq);
+        if (det < 0.0f)
+            continue;
+        if (FILTERED && !(B < 0.0f))
+            continue;
+        const float w = sphere_distance(B, det);
+        if (FILTERED && !(w < r.mag && w > 0.0f))
+            continue;
+        if (!found || w < d) {
+            d = w;
+            best = k;
+            found = true;
+        }
+    }
+    out[4 * i + 0] = og;
+    out[4 * i + 1] = __float_as_uint(dg);
+    out[4 * i + 2] = found ? S.sph_obj[best] : RT_NONE;
+    out[4 * i + 3] = __float_as_uint(found ? d : 0.0f);
+}
+
 } // namespace
 
 /* ------------------------------------------------------------------------------------------ */
@@ -1735,6 +1956,17 @@ void rt_launch_selftest_arith(const float *a, const float *b, const float *c, ui
 {
     if (n)
         k_selftest_arith<<<(n + RT_BLOCK - 1) / RT_BLOCK, RT_BLOCK, 0, stream>>>(a, b, c, n, out, out64);
+}
+
+void rt_launch_selftest_grid(const DevScene &S, const float *rays, uint32_t n, bool filtered, uint32_t *out,
+                             hipStream_t stream)
+{
+    if (!n)
+        return;
+    if (filtered)
+        k_selftest_grid<true><<<(n + RT_BLOCK - 1) / RT_BLOCK, RT_BLOCK, 0, stream>>>(S, rays, n, out);
+    else
+        k_selftest_grid<false><<<(n + RT_BLOCK - 1) / RT_BLOCK, RT_BLOCK, 0, stream>>>(S, rays, n, out);
 }
 
 void rt_launch_deinterleave(const uint32_t *gathered, uint32_t *frame, uint32_t width, uint32_t height,

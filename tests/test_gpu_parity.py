@@ -583,6 +583,37 @@ def test_c5_sparse_pins_tiled_scene(torch_cuda, golden, make_scene):
     ctx.close()
 
 
+def test_grid_search_equals_the_loop_over_every_sphere(torch_cuda, make_scene):
+    """Big scenes search their spheres through a uniform grid (rt_kernels.hip: grid_walk).  For 300 000
+    random rays - origins inside and outside the cloud, random and axis-parallel directions, and
+    directions that are NOT of unit length, which the reference's refraction formula produces and for
+    which its sphere test accepts a cone around the ray - the winner must be the one of the reference's
+    loop over all 16 384 spheres, distance bits included (rt_hip_selftest_grid runs both on the GPU)."""
+    torch = torch_cuda
+    sc = make_scene("c5")
+    ctx = rt.Context(queue_cap=1 << 20)
+    ctx.upload(sc)
+    rng = np.random.default_rng(5)
+    n = 150000
+    for filtered in (0, 1):
+        o = np.stack([rng.uniform(-16, 16, n), rng.uniform(-3, 12, n), rng.uniform(-70, 6, n)], 1)
+        d = rng.normal(size=(n, 3))
+        ax = rng.random(n) < 0.05
+        d[ax] = np.eye(3)[rng.integers(0, 3, ax.sum())] * rng.choice([-1, 1], ax.sum())[:, None]
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        d *= rng.choice([1.0, 1.0, 1.0, 0.9, 1.08, 1.0 + 3e-7], n)[:, None]
+        mag = rng.choice([9999999.9, 99999.9, 30.0, 5.0], n)
+        rays = torch.from_numpy(np.concatenate([o, d, mag[:, None]], 1).astype(np.float32)).cuda().contiguous()
+        out = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
+        _lib.check(_lib.load().rt_hip_selftest_grid(ctx._h, rays.data_ptr(), n, filtered, out.data_ptr()),
+                   "rt_hip_selftest_grid")
+        r = out.cpu().numpy().view(np.uint32)
+        bad = (r[:, 0] != r[:, 2]) | (r[:, 1] != r[:, 3])
+        assert not bad.any(), f"filtered={filtered}: {bad.sum()} rays differ, first {rays[np.nonzero(bad)[0][0]].tolist()}"
+        assert (r[:, 2] != 0xFFFFFFFF).mean() > 0.1          # the test rays do hit things
+    ctx.close()
+
+
 def test_device_math_is_ieee(torch_cuda):
     """The parity argument rests on IEEE-correct f32 sqrt / divide and on the double-precision
     islands being evaluated in double on the device.  Direct lighting of the checkerboard floor and
