@@ -12,7 +12,7 @@
 #define RT_MAX_LEVELS   64          /* supported recursion depth: 0 .. RT_MAX_LEVELS-2 */
 #define RT_NONE         0xFFFFFFFFu
 #define RT_LINK_NONE    0x1FFFFFFFu /* 29-bit "no parent / end of chain" */
-#define RT_TILE_SPHERES 2048        /* most spheres kept in LDS (32 KiB); scenes with more walk a grid */
+#define RT_TILE_SPHERES 128         /* most spheres searched by a loop over an LDS copy; scenes with more walk a grid in HBM */
 #define RT_MAX_POLY_LDS 1024        /* float4 slots for planes + info + vertices in LDS */
 #define RT_BLOCK        256
 /* per-thread parking area at the start of every trace kernel's LDS (row-major [word][thread],
