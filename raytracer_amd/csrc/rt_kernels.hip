@@ -423,7 +423,7 @@ __device__ __forceinline__ float phong_pow(float s, float ke)
 }
 
 /* Cooperative copy of n float4 from HBM to LDS by the whole block. */
-/* float4 slots of the sphere region of LDS: one tile, or (untiled) all spheres followed by their
+/* float4 slots of the sphere region of LDS: none for grid scenes, else all spheres followed by their
  * object indices (sph_obj), so that the closest-hit search never waits on a global load */
 __host__ __device__ __forceinline__ uint32_t sphere_slots(uint32_t nSph)
 {
@@ -606,10 +606,10 @@ __device__ __forceinline__ void wave_loop_all(const DevScene &S, bool need, cons
  * lane stops at its first accepted hit.  STATS disables that early exit and counts every test
  * the reference would make.
  *
- * TILED: more spheres than LDS holds (RT_TILE_SPHERES): the spheres are searched through a grid in
+ * GRID: more spheres than LDS holds (RT_TILE_SPHERES): the spheres are searched through a grid in
  * HBM (grid_walk) instead of a loop over all of them.
  */
-template <bool TILED, bool FILTERED, bool ANYHIT, bool STATS, bool BIG, bool EYE = false>
+template <bool GRID, bool FILTERED, bool ANYHIT, bool STATS, bool BIG, bool EYE = false>
 __device__ __forceinline__ void intersect_all(const DevScene &S, const float4 *lds_poly,
                                               float4 *lds_sph, bool active, const Ray &r,
                                               uint32_t exc_sph, uint32_t exc_poly, float &out_d,
@@ -619,7 +619,7 @@ __device__ __forceinline__ void intersect_all(const DevScene &S, const float4 *l
     /* EYE: the ray starts at the eye, like every primary ray, so the terms of the tests that depend on
      * the origin alone were evaluated once per block by stage_eye_terms (same expressions, same
      * rounding): (o - c, 4*(|o - c|^2 - r^2)) per sphere, -(n.o + F) per polygon. */
-    static_assert(!EYE || (!TILED && !BIG && !FILTERED), "eye terms: small untiled scenes, primary rays");
+    static_assert(!EYE || (!GRID && !BIG && !FILTERED), "eye terms: small scenes, primary rays");
     float d = 0.0f;
     uint32_t best_k = RT_NONE; /* winning sphere-list index */
     bool found = false;
@@ -659,7 +659,7 @@ __device__ __forceinline__ void intersect_all(const DevScene &S, const float4 *l
             }
         }
     };
-    if (TILED) {
+    if (GRID) {
         /* the grid is only exact for rays the reference's test treats (almost) geometrically: a
          * direction of unit length (shorter ones are fine too: the test then accepts LESS than
          * geometry, but the reported distance is off the sphere, so they walk without early exit) and
@@ -732,7 +732,7 @@ __device__ __forceinline__ void intersect_all(const DevScene &S, const float4 *l
 
     uint32_t best_obj = RT_NONE;
     if (!ANYHIT && found) {
-        if (TILED)
+        if (GRID)
             best_obj = S.sph_obj[best_k];
         else
             best_obj = ((const uint32_t *)(lds_sph + S.nSph))[best_k];
@@ -949,7 +949,7 @@ __device__ __forceinline__ void wave_add_total(uint64_t *stats, int slot, uint32
  * Returns true when the lane produced a tree node (index in node_idx); otherwise `leaf` holds
  * the clamped colour of a childless node.
  */
-template <bool TILED, bool STATS, bool TABLDS, typename EyeSource>
+template <bool GRID, bool STATS, bool TABLDS, typename EyeSource>
 __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCamera &C,
                                                 const DevWork &Wk, const float4 *lds_poly,
                                                 float4 *lds_sph, uint32_t *lds_vis, float *lds_park,
@@ -963,7 +963,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
 {
     node_idx = RT_NONE;
     spawn_r = spawn_t = false;
-    if (!TILED && !hit)
+    if (!GRID && !hit)
         return false;
 
     /*
@@ -1004,7 +1004,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
         tinypush(sh);
         float sd;
         uint32_t sobj;
-        intersect_all<TILED, true, true, STATS, !TABLDS>(S, lds_poly, lds_sph, hit, sh, exc_sph, exc_poly, sd,
+        intersect_all<GRID, true, true, STATS, !TABLDS>(S, lds_poly, lds_sph, hit, sh, exc_sph, exc_poly, sd,
                                                 sobj, tl);
         if (hit && sobj == RT_NONE)
             visible |= 1u << (l & 31u);
@@ -1075,8 +1075,8 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
         }
     }
     pc.mark(3);
-    if (!TILED && !hit)
-        return false; /* (tiled: every thread must reach the child searches below - block barriers) */
+    if (!GRID && !hit)
+        return false; /* (grid scenes: every lane must reach the child searches below - wave_loop_all needs whole waves) */
 
     /* material, object colour, normal and view vector for the combine and the spawn */
     const float4 mA = tab[rec + RT_OBJ_DIFFUSE];
@@ -1114,7 +1114,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     const bool want_t = hit && (kt != 0.0f) && (level != C.depth); /* raytrace.c:452 */
     spawn_r = want_r;
     spawn_t = want_t;
-    if (!TILED && !(want_r || want_t)) {
+    if (!GRID && !(want_r || want_t)) {
         leaf[0] = clamp1(outr); /* raytrace.c:562 */
         leaf[1] = clamp1(outg);
         leaf[2] = clamp1(outb);
@@ -1206,7 +1206,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
             cr.dx = back[3 * RT_BLOCK]; cr.dy = back[4 * RT_BLOCK]; cr.dz = back[5 * RT_BLOCK];
             cr.mag = back[6 * RT_BLOCK];
         }
-        intersect_all<TILED, true, false, STATS, !TABLDS>(S, lds_poly, lds_sph, want, cr, RT_NONE, RT_NONE, cd, cobj, tl);
+        intersect_all<GRID, true, false, STATS, !TABLDS>(S, lds_poly, lds_sph, want, cr, RT_NONE, RT_NONE, cd, cobj, tl);
         const bool chit = want && (cobj != RT_NONE);
         if (child == 0u) {
             hit_r = chit;
@@ -1420,7 +1420,7 @@ template <> __device__ __forceinline__ void fix_shape<1>(DevScene &S)
 /* ------------------------------------------------------------------------------------------ */
 /* k_primary: get_pixel_color + get_ray_color + depth-0 get_shade_color_phong, fused           */
 /* ------------------------------------------------------------------------------------------ */
-template <bool TILED, bool STATS, bool TABLDS, int SHAPE>
+template <bool GRID, bool STATS, bool TABLDS, int SHAPE>
 __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 : RT_WPE)) void k_primary(DevScene S, DevCamera C, DevWork Wk,
                                                       DevRows R)
 {
@@ -1436,7 +1436,7 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
     stage_camera(C, cam);
     stage_colours(S, kc);
     block_copy(lds_poly, S.poly, S.nPolySlots);
-    if (!TILED) {
+    if (!GRID) {
         block_copy(lds_sph, S.sph, S.nSph);
         for (uint32_t k = threadIdx.x; k < S.nSph; k += RT_BLOCK)
             ((uint32_t *)(lds_sph + S.nSph))[k] = S.sph_obj[k];
@@ -1479,7 +1479,7 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
 
             float d;
             uint32_t obj;
-            intersect_all<TILED, false, false, STATS, !TABLDS, TABLDS>(S, lds_poly, lds_sph, valid, r, RT_NONE,
+            intersect_all<GRID, false, false, STATS, !TABLDS, TABLDS>(S, lds_poly, lds_sph, valid, r, RT_NONE,
                                                               RT_NONE, d, obj, tl, eye_terms);
             const bool hit = valid && (obj != RT_NONE);
             float leaf[3] = {kc[KC_BG + 0], kc[KC_BG + 1], kc[KC_BG + 2]}; /* miss: raytrace.c:700-703 */
@@ -1487,7 +1487,7 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
             bool sr, st_;
             const float px = r.ox + r.dx * d, py = r.oy + r.dy * d, pz = r.oz + r.dz * d;
             const PrimaryEye eye_src{cam, fu0, fv0, i, j};
-            bool deferred = shade_and_spawn<TILED, STATS, TABLDS>(S, C, Wk, lds_poly, lds_sph, lds_vis, lds_park, kc, tab, hit,
+            bool deferred = shade_and_spawn<GRID, STATS, TABLDS>(S, C, Wk, lds_poly, lds_sph, lds_vis, lds_park, kc, tab, hit,
                                                           eye_src, px, py, pz, obj, 0u, RT_LINK_NONE << 3, shard,
                                                           node_base, Wk.capS, leaf, node, sr, st_, tl, pc);
             sc.add(hit, sr, st_);
@@ -1528,7 +1528,7 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
 /* ------------------------------------------------------------------------------------------ */
 /* k_bounce: one queued secondary ray per lane (reflection / transmission of level-1 nodes)    */
 /* ------------------------------------------------------------------------------------------ */
-template <bool TILED, bool STATS, bool TABLDS, int SHAPE>
+template <bool GRID, bool STATS, bool TABLDS, int SHAPE>
 __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_BOUNCE1 : RT_WPE)) void k_bounce(DevScene S, DevCamera C, DevWork Wk,
                                                      uint32_t level)
 {
@@ -1554,7 +1554,7 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_BOUNCE1 : RT_WPE)) v
     __shared__ float kc[KC_WORDS];
     stage_colours(S, kc);
     block_copy(lds_poly, S.poly, S.nPolySlots);
-    if (!TILED) {
+    if (!GRID) {
         block_copy(lds_sph, S.sph, S.nSph);
         for (uint32_t k = threadIdx.x; k < S.nSph; k += RT_BLOCK)
             ((uint32_t *)(lds_sph + S.nSph))[k] = S.sph_obj[k];
@@ -1623,7 +1623,7 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_BOUNCE1 : RT_WPE)) v
         bool sr, st_;
         StashedEye::park(lds_eye, r);
         const StashedEye eye_src{lds_eye};
-        const bool deferred = shade_and_spawn<TILED, STATS, TABLDS>(S, C, Wk, lds_poly, lds_sph, lds_vis, lds_park, kc, tab, hit, eye_src,
+        const bool deferred = shade_and_spawn<GRID, STATS, TABLDS>(S, C, Wk, lds_poly, lds_sph, lds_vis, lds_park, kc, tab, hit, eye_src,
                                                             px, py, pz, obj, level,
                                                             ((parent >> 1) << 3) | (parent & 1u), shard, node_base,
                                                             node_room, leaf, node, sr, st_, tl, pc);
@@ -1869,10 +1869,10 @@ void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk,
 {
     const dim3 grid((C.W + 31u) / 32u, R.ntiles);
     const size_t lds = rt_scene_lds_bytes(S);
-    const bool tiled = S.nSph > RT_TILE_SPHERES;
-    /* three scene classes: small (everything in LDS), mid (spheres in LDS, tables in HBM), tiled */
+    const bool grid_scene = S.nSph > RT_TILE_SPHERES;
+    /* three scene classes: small (everything in LDS), mid (spheres in LDS, tables in HBM), grid (spheres in HBM) */
     void (*kernel)(DevScene, DevCamera, DevWork, DevRows) =
-        tiled ? (stats ? k_primary<true, true, false, 0> : k_primary<true, false, false, 0>)
+        grid_scene ? (stats ? k_primary<true, true, false, 0> : k_primary<true, false, false, 0>)
         : rt_scene_shape(S) == 1 ? (stats ? k_primary<false, true, true, 1> : k_primary<false, false, true, 1>)
         : S.tabInLds ? (stats ? k_primary<false, true, true, 0> : k_primary<false, false, true, 0>)
                      : (stats ? k_primary<false, true, false, 0> : k_primary<false, false, false, 0>);
@@ -1924,9 +1924,9 @@ void rt_launch_bounce(const DevScene &S, const DevCamera &C, const DevWork &Wk, 
                       bool stats, uint32_t expect, hipStream_t stream)
 {
     const size_t lds = rt_scene_lds_bytes(S);
-    const bool tiled = S.nSph > RT_TILE_SPHERES;
+    const bool grid_scene = S.nSph > RT_TILE_SPHERES;
     void (*kernel)(DevScene, DevCamera, DevWork, uint32_t) =
-        tiled ? (stats ? k_bounce<true, true, false, 0> : k_bounce<true, false, false, 0>)
+        grid_scene ? (stats ? k_bounce<true, true, false, 0> : k_bounce<true, false, false, 0>)
         : rt_scene_shape(S) == 1 ? (stats ? k_bounce<false, true, true, 1> : k_bounce<false, false, true, 1>)
         : S.tabInLds ? (stats ? k_bounce<false, true, true, 0> : k_bounce<false, false, true, 0>)
                      : (stats ? k_bounce<false, true, false, 0> : k_bounce<false, false, false, 0>);
