@@ -716,25 +716,40 @@ void build_grid(const std::vector<float4> &sph, const rt_scene *sc, const std::v
         vol *= ext[a];
     }
     const char *dens = getenv("RT_HIP_GRID_DENSITY"); /* development: spheres per cell aimed at */
-    const double per_cell = dens && atof(dens) > 0.0 ? atof(dens) : 0.5; /* measured: 0.5 .. 2 within 10 % */
-    const double cell = cbrt(vol * per_cell / (double)n);
-    GridHeader G;
-    size_t cells = 1;
-    for (int a = 0; a < 3; ++a) {
-        long dm = lround(ext[a] / cell);
-        dm = dm < 1 ? 1 : (dm > 128 ? 128 : dm);
-        G.dim[a] = (uint32_t)dm;
-        G.gmin[a] = (float)lo[a];
-        G.gmax[a] = (float)hi[a];
-        G.h[a] = (float)(ext[a] / (double)dm);
-        G.inv_h[a] = (float)((double)dm / ext[a]);
-        cells *= (size_t)dm;
-    }
-    G.words = (uint32_t)(sizeof(GridHeader) / sizeof(uint32_t));
+    double per_cell = dens && atof(dens) > 0.0 ? atof(dens) : 0.5; /* measured: 0.5 .. 2 within 10 % */
     /* rays whose origin is within 1.5 box diagonals of the box centre are at most `reach` = 2 diagonals
      * from any sphere: what the reference's test accepts beyond geometry at that reach (GridHeader) */
     const double diag = sqrt(ext[0] * ext[0] + ext[1] * ext[1] + ext[2] * ext[2]);
     const double reach = 2.0 * diag, extra2 = 2.0 * (double)RT_GRID_KAPPA * reach * reach;
+    GridHeader G;
+    size_t cells = 1;
+    for (;;) { /* coarser until the lists stay small: big or clustered spheres overlap many fine cells */
+        const double cell = cbrt(vol * per_cell / (double)n);
+        cells = 1;
+        double listed = 0.0; /* estimate of the list entries: cells overlapped per sphere */
+        for (int a = 0; a < 3; ++a) {
+            long dm = lround(ext[a] / cell);
+            dm = dm < 1 ? 1 : (dm > 128 ? 128 : dm);
+            G.dim[a] = (uint32_t)dm;
+            G.gmin[a] = (float)lo[a];
+            G.gmax[a] = (float)hi[a];
+            G.h[a] = (float)(ext[a] / (double)dm);
+            G.inv_h[a] = (float)((double)dm / ext[a]);
+            cells *= (size_t)dm;
+        }
+        for (size_t k = 0; k < n; ++k) {
+            double per = 1.0;
+            for (int a = 0; a < 3; ++a) {
+                const double span = 2.0 * (sqrt(rad[k] * rad[k] + extra2) + 0.01 * (double)G.h[a]);
+                per *= fmin((double)G.dim[a], floor(span / (double)G.h[a]) + 2.0);
+            }
+            listed += per;
+        }
+        if (listed <= 64.0 * (double)n || cells == 1)
+            break;
+        per_cell *= 8.0;
+    }
+    G.words = (uint32_t)(sizeof(GridHeader) / sizeof(uint32_t));
     for (int a = 0; a < 3; ++a)
         G.centre[a] = (float)(0.5 * (lo[a] + hi[a]));
     G.origin_reach2 = (float)(1.5 * diag * 1.5 * diag);
