@@ -65,6 +65,12 @@ def set_rounded_pow(on):
     oracle().rt_oracle_set_rounded_pow(int(bool(on)))
 
 
+def set_shading(model):
+    """0: get_shade_color_phong (what the reference calls, raytrace.c:706); 1: its unused older routine
+    get_shade_color_phongblinn (raytrace.c:574-685)"""
+    oracle().rt_oracle_set_shading(int(model))
+
+
 def tone(rgb, op, ld_max, l_max, key_pixel=-1, wide_sums=False):
     """rt_oracle_tone (apply_tone, raytrace.c:792-871) on a copy of rgb[..., 3]; returns (rgb, sums).
     wide_sums: diagnostic variant with the two frame-wide sums in double (see rt_oracle.c)."""

@@ -371,6 +371,77 @@ static rt_color shade(const ctx_t *c, const rt_object3d *obj, const ray_t *eye, 
     return out;
 }
 
+/* get_shade_color_phongblinn  raytrace.c:574-685: the reference's older shading routine, which nothing
+ * calls (get_ray_color calls get_shade_color_phong, :706).  Local illumination only: the material's
+ * diffuse colour (no checkerboard, :589), shadow rays that are NOT pushed off the surface (:613-616),
+ * the halfway vector H = (V+S) * (1.0 / |V+S|) in place of the mirror direction (:632-634, :647),
+ * no reflection, no transmission. */
+static rt_color shade_blinn(const ctx_t *c, const rt_object3d *obj, const ray_t *eye, v3 pt)
+{
+    const rt_scene *sc = c->scene;
+    const rt_material *m = &obj->material;
+    const rt_color *dc = &m->colors[RT_MATERIAL_DIFFUSECOLOR];
+    rt_color out, diff = {0, 0, 0}, spec = {0, 0, 0};
+
+    c->cnt->shade_nodes++;
+    c->cnt->nodes_at_depth[0]++;
+    if (obj->geometryType == RT_GEOMETRY_SPHERE)
+        c->cnt->nodes_sphere++;
+    else
+        c->cnt->nodes_polygon++;
+
+    out.r = dc->r * sc->ambientLightColor.r; /* :589-593 */
+    out.g = dc->g * sc->ambientLightColor.g;
+    out.b = dc->b * sc->ambientLightColor.b;
+    out.r = out.r * m->phong_ka;
+    out.g = out.g * m->phong_ka;
+    out.b = out.b * m->phong_ka;
+
+    v3 N = object_normal(obj, pt);
+    v3 V = normalize(sub(eye->origin, pt)); /* :604-606 */
+
+    for (uint32_t i = 0; i < sc->nLights; ++i) { /* :609-663 */
+        const rt_pointlight *L = &sc->lights[i];
+        ray_t shadow = ray_create(pt, v3_from(&L->position));
+        c->cnt->shadow_rays++;
+        v3 hp;
+        float hd;
+        if (closest_excl(c, &shadow, obj, &hp, &hd))
+            continue;
+        v3 S = shadow.direction;
+        v3 tmp = add(V, S);
+        float inv = (float)(1.0 / (double)magnitude(tmp)); /* :633 double quotient stored to float */
+        v3 H = scale(tmp, inv);
+        float t = dot(S, N);
+        if (t <= 0.0f)
+            continue;
+        c->cnt->lights_lit++;
+        diff.r += L->color.r * t;
+        diff.g += L->color.g * t;
+        diff.b += L->color.b * t;
+        float s = dot(H, N);
+        if (s < 0.0f)
+            s = 0.0f;
+        s = g_rounded_pow ? rounded_pow(s, m->phong_ke) : powf(s, m->phong_ke);
+        spec.r += L->color.r * s;
+        spec.g += L->color.g * s;
+        spec.b += L->color.b * s;
+    }
+    const rt_color *sp = &m->colors[RT_MATERIAL_SPECULARCOLOR];
+    out.r += m->phong_kd * diff.r * dc->r + m->phong_ks * spec.r * sp->r; /* :669-680 */
+    out.g += m->phong_kd * diff.g * dc->g + m->phong_ks * spec.g * sp->g;
+    out.b += m->phong_kd * diff.b * dc->b + m->phong_ks * spec.b * sp->b;
+    if (out.r > 1.0f) out.r = 1.0f; /* :683 */
+    if (out.g > 1.0f) out.g = 1.0f;
+    if (out.b > 1.0f) out.b = 1.0f;
+    return out;
+}
+
+/* which of the reference's two shading routines get_ray_color calls: 0 = get_shade_color_phong (what
+ * the reference does, raytrace.c:706), 1 = get_shade_color_phongblinn */
+static int g_shading;
+void rt_oracle_set_shading(int model) { g_shading = model; }
+
 /* get_ray_color  raytrace.c:688-708 */
 static rt_color ray_color(const ctx_t *c, const ray_t *ray)
 {
@@ -379,6 +450,8 @@ static rt_color ray_color(const ctx_t *c, const ray_t *ray)
     const rt_object3d *obj = closest(c, ray, &pt, &d);
     if (!obj)
         return c->scene->bgColor;
+    if (g_shading == 1)
+        return shade_blinn(c, obj, ray, pt);
     return shade(c, obj, ray, pt, 0);
 }
 

@@ -36,6 +36,23 @@ def make_scene(golden):
     return _make
 
 
+def blinn_cases():
+    """(case, scene, expected argb, expected radiance) of tests/golden/blinn.npz: the reference's unused
+    second shading routine (raytrace.c:574-685), fixtures made by tests/golden/make_golden_blinn.py."""
+    import json
+    import raytracer_amd as rt
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    meta = json.load(open(os.path.join(here, "blinn.json")))
+    arrays = np.load(os.path.join(here, "blinn.npz"))
+    for c in meta["cases"]:
+        if c["scene"].endswith(".scene"):
+            sc = rt.load_scene(os.path.join(here, c["scene"]))
+        else:
+            a = meta["scenes"][c["scene"]]
+            sc = rt.Scene.builtin() if a is None else rt.Scene.synthetic(**a)
+        yield c, sc, arrays[c["key"] + "_argb"], arrays[c["key"] + "_rad"]
+
+
 def rgb_bytes(argb):
     return np.stack([(argb >> 16) & 255, (argb >> 8) & 255, argb & 255], -1).astype(np.int32)
 

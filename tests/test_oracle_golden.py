@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import ppm_md5
+from conftest import blinn_cases, ppm_md5
 from oracle import oracle_py as O
 from raytracer_amd import _abi as A
 
@@ -160,3 +160,25 @@ def test_tone_step_equals_the_reference_bit_for_bit(golden):
         out, sums = O.tone(arrays[c["input"]], c["op"], c["ldMax"], c["lMax"], c["keyPix"])
         assert np.array_equal(out.view(np.uint32), want[c["key"]].view(np.uint32)), c["key"]
         assert np.isfinite(sums).all()
+
+
+def test_second_shading_routine_equals_the_reference_bit_for_bit():
+    """get_shade_color_phongblinn (raytrace.c:574-685): the restatement against frames the compiled
+    reference rendered with that routine (tests/golden/make_golden_blinn.py)."""
+    n = 0
+    O.set_shading(1)
+    try:
+        for c, sc, argb_ref, rad_ref in blinn_cases():
+            cam = O.prepare_camera(sc.c, c["W"], c["H"], c["sqrtSpp"], 8)
+            argb, rad, cnt = O.render(sc.c, cam, nthreads=8)
+            assert np.array_equal(argb, argb_ref), c["key"]
+            assert np.array_equal(rad.view(np.uint32), rad_ref.view(np.uint32)), c["key"]
+            assert cnt["shade_nodes"] == c["shade_nodes"]
+            assert cnt["primary_rays"] + cnt["shadow_rays"] == c["counts"]["ray_create"]
+            assert cnt["reflection_rays"] == cnt["transmission_rays"] == 0
+            assert cnt["sphere_tests"] == c["counts"]["sphere_tests"]
+            assert cnt["polygon_tests"] == c["counts"]["polygon_tests"]
+            n += 1
+    finally:
+        O.set_shading(0)
+    assert n == 6
