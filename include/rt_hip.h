@@ -260,6 +260,17 @@ int  rt_hip_render_stats(rt_hip_ctx *ctx, const rt_camera *camera,
                          uint32_t *d_argb, float *d_radiance,
                          uint32_t row0, uint32_t nrows, void *stream, rt_hip_stats *stats);
 
+/* Which of the reference's two shading routines the context's renders use: RT_SHADE_PHONG =
+ * get_shade_color_phong (raytrace.c:282-564, the one get_ray_color calls at :706; the default) or
+ * RT_SHADE_PHONGBLINN = get_shade_color_phongblinn (raytrace.c:574-685, kept in the reference but called
+ * by nothing): local illumination only - material colour without the checkerboard, shadow rays that are
+ * not pushed off the surface, halfway-vector highlight, no reflection or transmission (depth is ignored).
+ * rt_hip_render / raytrace() follow RT_HIP_SHADING=phong|phongblinn in the environment.
+ * Returns 0 or RT_E_INVALID. */
+#define RT_SHADE_PHONG       0
+#define RT_SHADE_PHONGBLINN  1
+int  rt_hip_ctx_set_shading(rt_hip_ctx *ctx, int model);
+
 /* Bracket the fused primary kernel with HIP events on the render stream (k0_ms). */
 void rt_hip_ctx_set_timing(rt_hip_ctx *ctx, int enable);
 /* Cap on primary samples per image batch (0 = automatic). */

@@ -118,6 +118,7 @@ def render(scene, cam, row0=0, nrows=None, want_radiance=True, devices=None):
 
 
 TONE_WARD, TONE_REINHARD = 1, 2
+SHADE_PHONG, SHADE_PHONGBLINN = 0, 1
 
 
 def tone(d_radiance, d_argb, npixels, op, ld_max, l_max, key_pixel=-1, stream=0):
@@ -154,6 +155,11 @@ class Context:
 
     def set_timing(self, on):
         load().rt_hip_ctx_set_timing(self._h, int(bool(on)))
+
+    def set_shading(self, model):
+        """SHADE_PHONG (get_shade_color_phong, what the reference calls) or SHADE_PHONGBLINN (its unused
+        get_shade_color_phongblinn, raytrace.c:574-685)"""
+        check(load().rt_hip_ctx_set_shading(self._h, int(model)), "rt_hip_ctx_set_shading")
 
     def set_batch_samples(self, n):
         load().rt_hip_ctx_set_batch_samples(self._h, int(n))

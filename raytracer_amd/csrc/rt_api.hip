@@ -89,6 +89,7 @@ struct rt_hip_ctx {
     std::vector<Batch> todo;         /* batches still to enqueue                      */
     /* options */
     bool timing = false;
+    int shading = RT_SHADE_PHONG;
     uint64_t batch_samples = 0;
     std::vector<hipEvent_t> ev; /* 2 per batch when timing */
     hipEvent_t round_done = nullptr; /* recorded behind each round's counter copy: drain() waits for
@@ -198,7 +199,7 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
         c->ev.push_back(e1);
         HIP_TRY(hipEventRecord(e0, st));
     }
-    rt_launch_primary(c->S, c->C, Wk, R, stats, st);
+    rt_launch_primary(c->S, c->C, Wk, R, stats, c->shading == RT_SHADE_PHONGBLINN, st);
     if (timed)
         HIP_TRY(hipEventRecord(c->ev.back(), st));
     const uint32_t depth = c->C.depth;
@@ -572,6 +573,16 @@ void rt_hip_ctx_set_timing(rt_hip_ctx *c, int enable)
 {
     if (c)
         c->timing = enable != 0;
+}
+
+int rt_hip_ctx_set_shading(rt_hip_ctx *c, int model)
+{
+    if (!c || (model != RT_SHADE_PHONG && model != RT_SHADE_PHONGBLINN)) {
+        set_err("shading model %d is neither RT_SHADE_PHONG nor RT_SHADE_PHONGBLINN", model);
+        return RT_E_INVALID;
+    }
+    c->shading = model;
+    return 0;
 }
 
 void rt_hip_ctx_set_batch_samples(rt_hip_ctx *c, uint64_t max_samples)
@@ -953,6 +964,14 @@ static int submit(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb, float *
     int rc = ctx_set_device(c);
     if (rc)
         return rc;
+    /* get_shade_color_phongblinn spawns nothing (raytrace.c:574-685): with depth 0 the pipeline is
+     * k_primary -> k_resolve, no bounce and no fold launches */
+    rt_camera flat_cam;
+    if (c->shading == RT_SHADE_PHONGBLINN) {
+        flat_cam = *cam;
+        flat_cam.depth = 0;
+        cam = &flat_cam;
+    }
     if (c->pending) { /* the previous render's counters were never collected: drain it */
         rc = rt_hip_finish(c, nullptr);
         if (rc)
@@ -968,7 +987,8 @@ static int submit(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb, float *
     {
         const uint64_t key[3] = {((uint64_t)cam->frameBufferWidth << 32) | cam->frameBufferHeight,
                                  ((uint64_t)cam->sqrtSpp << 32) | cam->depth,
-                                 ((uint64_t)job.ntiles << 32) | (job.interleaved ? job.nphases : 0u)};
+                                 ((uint64_t)job.ntiles << 32) | ((uint64_t)c->shading << 16) |
+                                     (job.interleaved ? job.nphases : 0u)};
         if (memcmp(key, c->seen_key, sizeof key) != 0) {
             memcpy(c->seen_key, key, sizeof key);
             c->seen_valid = false;
@@ -1143,6 +1163,18 @@ int staged_copy_back(void *dst, const void *d_src, size_t bytes)
 }
 } // namespace
 
+/* RT_HIP_SHADING=phongblinn: the host-pointer entry points shade with the reference's older routine (the
+ * reference itself switches by editing the call at raytrace.c:706) */
+static int shading_from_env(void)
+{
+    const char *e = getenv("RT_HIP_SHADING");
+    if (!e || !*e || !strcmp(e, "phong"))
+        return RT_SHADE_PHONG;
+    if (!strcmp(e, "phongblinn") || !strcmp(e, "blinn"))
+        return RT_SHADE_PHONGBLINN;
+    return -1; /* rejected by rt_hip_ctx_set_shading */
+}
+
 int rt_hip_render(const rt_scene *scene, const rt_camera *cam, rt_framebuffer *fb)
 {
     if (!scene || !cam || !fb || !fb->argb) {
@@ -1170,6 +1202,9 @@ int rt_hip_render(const rt_scene *scene, const rt_camera *cam, rt_framebuffer *f
         if (rc)
             return rc;
     }
+    rc = rt_hip_ctx_set_shading(g_ctx, shading_from_env());
+    if (rc)
+        return rc;
     rc = rt_hip_scene_upload(g_ctx, scene);
     if (rc)
         return rc;
@@ -1301,7 +1336,7 @@ int rt_hip_render_devices(const rt_scene *scene, const rt_camera *cam, rt_frameb
             break;
         if (!s.stream)
             HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-        if ((rc = rt_hip_scene_upload(s.ctx, scene)))
+        if ((rc = rt_hip_ctx_set_shading(s.ctx, shading_from_env())) || (rc = rt_hip_scene_upload(s.ctx, scene)))
             break;
         if (local_px > s.argb_px) {
             if (s.d_argb) (void)hipFree(s.d_argb);

@@ -183,7 +183,7 @@ static_assert(2 * ST_COUNT <= CNT_STATS_STRIDE, "statistics do not fit their lin
 
 /* launch wrappers implemented in rt_kernels.hip (all asynchronous on `stream`) */
 void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
-                       bool stats, hipStream_t stream);
+                       bool stats, bool blinn, hipStream_t stream);
 /* `expect` = entries per shard the launch is expected to find (0 = unknown: a full resident set).
  * It only sizes the grid; the kernels stride over whatever the counters say. */
 void rt_launch_bounce(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t level,

@@ -949,7 +949,7 @@ __device__ __forceinline__ void wave_add_total(uint64_t *stats, int slot, uint32
  * Returns true when the lane produced a tree node (index in node_idx); otherwise `leaf` holds
  * the clamped colour of a childless node.
  */
-template <bool GRID, bool STATS, bool TABLDS, typename EyeSource>
+template <bool GRID, bool STATS, bool TABLDS, bool BLINN = false, typename EyeSource>
 __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCamera &C,
                                                 const DevWork &Wk, const float4 *lds_poly,
                                                 float4 *lds_sph, uint32_t *lds_vis, float *lds_park,
@@ -1001,7 +1001,8 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
         sh.mag = mag3(sh.dx, sh.dy, sh.dz);
         const float inv = recip_rn(sh.mag);
         sh.dx = sh.dx * inv; sh.dy = sh.dy * inv; sh.dz = sh.dz * inv;
-        tinypush(sh);
+        if constexpr (!BLINN) /* raytrace.c:613-616: the older routine does not push its shadow rays */
+            tinypush(sh);
         float sd;
         uint32_t sobj;
         intersect_all<GRID, true, true, STATS, !TABLDS>(S, lds_poly, lds_sph, hit, sh, exc_sph, exc_poly, sd,
@@ -1062,10 +1063,18 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
                 const float t = dot3(sx, sy, sz, Nx, Ny, Nz);
                 if (!(t <= 0.0f)) {
                     tl.lit();
-                    const float t2 = 2.0f * t;
-                    const float Rx = Nx * t2 - sx, Ry = Ny * t2 - sy, Rz = Nz * t2 - sz;
                     dfr += lc.x * t; dfg += lc.y * t; dfb += lc.z * t;
-                    float s = dot3(Rx, Ry, Rz, Vx, Vy, Vz);
+                    float s;
+                    if constexpr (BLINN) { /* halfway vector raytrace.c:632-634,647; the double quotient
+                                              1.0 / |V+S| stored to float is the rounded float quotient */
+                        const float hx = Vx + sx, hy = Vy + sy, hz = Vz + sz;
+                        const float inv = recip_rn(mag3(hx, hy, hz));
+                        s = dot3(hx * inv, hy * inv, hz * inv, Nx, Ny, Nz);
+                    } else {
+                        const float t2 = 2.0f * t;
+                        const float Rx = Nx * t2 - sx, Ry = Ny * t2 - sy, Rz = Nz * t2 - sz;
+                        s = dot3(Rx, Ry, Rz, Vx, Vy, Vz);
+                    }
                     if (s < 0.0f)
                         s = 0.0f;
                     s = phong_pow(s, ke);
@@ -1087,7 +1096,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
 
     /* get_object_color object3d.c:64-117 */
     float ocr, ocg, ocb;
-    if (is_sphere) {
+    if (BLINN || is_sphere) { /* raytrace.c:589,669-680: the older routine takes the material's colour for polygons too */
         ocr = mA.x; ocg = mA.y; ocb = mA.z;
     } else {
         /* get_2dproject_position object3d.c:30-39; quotients by constants: any reciprocal within
@@ -1110,11 +1119,13 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     outb += (mC.x * dfb) * ocb + (mB.w * spb) * mB.z;
 
     const float kr = mC.z, kt = mC.w;
-    const bool want_r = hit && (kr != 0.0f) && (level != C.depth); /* raytrace.c:405 */
-    const bool want_t = hit && (kt != 0.0f) && (level != C.depth); /* raytrace.c:452 */
+    const bool want_r = !BLINN && hit && (kr != 0.0f) && (level != C.depth); /* raytrace.c:405 */
+    const bool want_t = !BLINN && hit && (kt != 0.0f) && (level != C.depth); /* raytrace.c:452 */
     spawn_r = want_r;
     spawn_t = want_t;
-    if (!GRID && !(want_r || want_t)) {
+    if ((BLINN || !GRID) && !(want_r || want_t)) { /* (the older routine never spawns: raytrace.c:683-684) */
+        if (!hit)
+            return false;
         leaf[0] = clamp1(outr); /* raytrace.c:562 */
         leaf[1] = clamp1(outg);
         leaf[2] = clamp1(outb);
@@ -1420,7 +1431,7 @@ template <> __device__ __forceinline__ void fix_shape<1>(DevScene &S)
 /* ------------------------------------------------------------------------------------------ */
 /* k_primary: get_pixel_color + get_ray_color + depth-0 get_shade_color_phong, fused           */
 /* ------------------------------------------------------------------------------------------ */
-template <bool GRID, bool STATS, bool TABLDS, int SHAPE>
+template <bool GRID, bool STATS, bool TABLDS, int SHAPE, bool BLINN = false>
 __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 : RT_WPE)) void k_primary(DevScene S, DevCamera C, DevWork Wk,
                                                       DevRows R)
 {
@@ -1487,7 +1498,7 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
             bool sr, st_;
             const float px = r.ox + r.dx * d, py = r.oy + r.dy * d, pz = r.oz + r.dz * d;
             const PrimaryEye eye_src{cam, fu0, fv0, i, j};
-            bool deferred = shade_and_spawn<GRID, STATS, TABLDS>(S, C, Wk, lds_poly, lds_sph, lds_vis, lds_park, kc, tab, hit,
+            bool deferred = shade_and_spawn<GRID, STATS, TABLDS, BLINN>(S, C, Wk, lds_poly, lds_sph, lds_vis, lds_park, kc, tab, hit,
                                                           eye_src, px, py, pz, obj, 0u, RT_LINK_NONE << 3, shard,
                                                           node_base, Wk.capS, leaf, node, sr, st_, tl, pc);
             sc.add(hit, sr, st_);
@@ -1865,11 +1876,19 @@ size_t rt_scene_lds_bytes(const DevScene &S)
 }
 
 void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
-                       bool stats, hipStream_t stream)
+                       bool stats, bool blinn, hipStream_t stream)
 {
     const dim3 grid((C.W + 31u) / 32u, R.ntiles);
     const size_t lds = rt_scene_lds_bytes(S);
     const bool grid_scene = S.nSph > RT_TILE_SPHERES;
+    if (blinn) { /* get_shade_color_phongblinn (raytrace.c:574-685): the generic kernels only */
+        void (*kernel)(DevScene, DevCamera, DevWork, DevRows) =
+            grid_scene ? (stats ? k_primary<true, true, false, 0, true> : k_primary<true, false, false, 0, true>)
+            : S.tabInLds ? (stats ? k_primary<false, true, true, 0, true> : k_primary<false, false, true, 0, true>)
+                         : (stats ? k_primary<false, true, false, 0, true> : k_primary<false, false, false, 0, true>);
+        kernel<<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, R);
+        return;
+    }
     /* three scene classes: small (everything in LDS), mid (spheres in LDS, tables in HBM), grid (spheres in HBM) */
     void (*kernel)(DevScene, DevCamera, DevWork, DevRows) =
         grid_scene ? (stats ? k_primary<true, true, false, 0> : k_primary<true, false, false, 0>)

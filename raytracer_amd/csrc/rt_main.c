@@ -12,6 +12,8 @@
  *     --gpus N              spread the frame over HIP devices 0..N-1 (rt_hip_render_devices)
  *     --devices a,b,...     the same with an explicit device list
  *     --dump-radiance FILE  also write the un-quantised radiance: W*H*3 float32, row 0 on top
+ *     --shading MODEL       phong (get_shade_color_phong, what the reference calls, raytrace.c:706) or
+ *                           phongblinn (its unused get_shade_color_phongblinn, raytrace.c:574-685)
  * The run time is printed with sub-second resolution (the reference's time() has whole seconds).
  */
 #include "rt_hip.h"
@@ -76,6 +78,13 @@ int main(int argc, char **argv)
             }
         } else if (!strcmp(argv[a], "--dump-radiance") && a + 1 < argc) {
             radiance_out = argv[++a];
+        } else if (!strcmp(argv[a], "--shading") && a + 1 < argc) {
+            ++a;
+            if (strcmp(argv[a], "phong") && strcmp(argv[a], "phongblinn")) {
+                printf("--shading takes phong or phongblinn\n");
+                return 1;
+            }
+            setenv("RT_HIP_SHADING", argv[a], 1); /* what raytrace() / rt_hip_render_devices follow */
         } else {
             printf("unknown option %s\n", argv[a]);
             return 1;

@@ -252,6 +252,18 @@ def test_command_line_host(golden, tmp_path):
     sc = rt.Scene.builtin()
     _, want = rt.render(sc, rt.prepare_camera(sc, 640, 480, 1, 4))
     assert np.array_equal(rad.view(np.uint32), want.view(np.uint32))
+    # --shading phongblinn: the frame the reference build rendered with its second routine
+    from conftest import blinn_cases
+    c, _, argb_ref, _ = next(blinn_cases())
+    assert c["scene"] == "builtin"
+    out3 = tmp_path / "c.ppm"
+    p = subprocess.run([exe, str(out3), scene, str(c["W"]), str(c["H"]), str(c["sqrtSpp"]), "8", "--shading",
+                        "phongblinn"], capture_output=True, text=True, timeout=110)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert hashlib.md5(out3.read_bytes()).hexdigest() == ppm_md5(argb_ref, c["W"], c["H"])
+    p = subprocess.run([exe, str(out3), scene, "8", "8", "1", "1", "--shading", "flat"], capture_output=True, text=True,
+                       timeout=110)
+    assert p.returncode == 1 and "--shading takes phong or phongblinn" in p.stdout
 
 
 def test_tone_step_against_reference_fixtures_and_in_two_halves(torch_cuda, golden):
@@ -738,3 +750,70 @@ def test_loaded_scene_files_render_like_the_builtin_and_like_the_oracle():
         a_o, r_o, _ = O.render(sc.c, cam, nthreads=16)
         assert_parity(argb, rad, a_o, r_o, f"triangle_two_lights {W}x{H} s{s} d{d}")
         assert len(np.unique(argb)) > 500            # an actual picture, not a flat frame
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's second shading routine, get_shade_color_phongblinn (raytrace.c:574-685)
+# ---------------------------------------------------------------------------------------------
+
+def test_second_shading_routine_against_reference_fixtures(monkeypatch):
+    """Frames the compiled reference rendered with get_shade_color_phongblinn in place of
+    get_shade_color_phong (tests/golden/make_golden_blinn.py); the host-pointer entry point switches with
+    RT_HIP_SHADING."""
+    from conftest import blinn_cases
+    monkeypatch.setenv("RT_HIP_SHADING", "phongblinn")
+    n = 0
+    for c, sc, argb_ref, rad_ref in blinn_cases():
+        cam = rt.prepare_camera(sc, c["W"], c["H"], c["sqrtSpp"], 8)
+        argb, rad = rt.render(sc, cam)
+        assert_parity(argb, rad, argb_ref, rad_ref, c["key"])
+        n += 1
+    assert n == 6
+    monkeypatch.setenv("RT_HIP_SHADING", "gouraud")
+    with pytest.raises(rt.RtHipError):
+        rt.render(sc, cam)
+    monkeypatch.delenv("RT_HIP_SHADING")
+    argb2, _ = rt.render(sc, cam)  # back to get_shade_color_phong: another picture
+    assert not np.array_equal(argb2, argb)
+
+
+@pytest.mark.parametrize("name,W,H,s", [
+    ("builtin", 640, 480, 2), ("builtin", 1920, 1080, 4), ("builtin", 33, 9, 1),
+    ("syn64", 160, 120, 2), ("syn300", 128, 96, 2), ("syn3000", 96, 64, 2),
+])
+def test_second_shading_routine_is_bit_identical_and_counts_match(torch_cuda, make_scene, name, W, H, s):
+    """Small, mid and grid scene classes through the device-resident interface: every pixel's radiance
+    equals the oracle's bit for bit (with its correctly rounded power, as for the main routine), and the
+    counters say what the routine does: one unpushed shadow ray per node and light, nothing spawned."""
+    torch = torch_cuda
+    sc = make_scene(name)
+    cam = rt.prepare_camera(sc, W, H, s, 8)
+    ctx = rt.Context()
+    ctx.upload(sc)
+    ctx.set_shading(rt.SHADE_PHONGBLINN)
+    argb = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    rad = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    st = ctx.render_stats(cam, argb.data_ptr(), rad.data_ptr())
+    argb2 = torch.zeros_like(argb)
+    ctx.render_rows(cam, argb2.data_ptr())
+    ctx.finish()
+    O.set_rounded_pow(True)
+    O.set_shading(1)
+    try:
+        a_o, r_o, cnt = O.render(sc.c, cam, nthreads=16)
+    finally:
+        O.set_shading(0)
+        O.set_rounded_pow(False)
+    got = rad.cpu().numpy()
+    differ = (got.view(np.uint32) != r_o.view(np.uint32)).any(-1)
+    assert differ.sum() == 0, f"{differ.sum()} pixels differ, first at {np.argwhere(differ)[:4].tolist()}"
+    assert np.array_equal(argb.cpu().numpy().view(np.uint32), a_o)
+    assert torch.equal(argb, argb2)  # the plain kernels give the instrumented kernels' pixels
+    assert st.shade_nodes == cnt["shade_nodes"] and st.shadow_rays == cnt["shadow_rays"]
+    assert st.reflection_rays == 0 and st.transmission_rays == 0 and st.tree_nodes == 0
+    if name in ("builtin", "syn64"):  # (big scenes search a grid: fewer sphere tests than the reference's loop)
+        assert st.sphere_tests == cnt["sphere_tests"] and st.polygon_tests == cnt["polygon_tests"]
+    assert st.lights_lit == cnt["lights_lit"]
+    with pytest.raises(rt.RtHipError):
+        ctx.set_shading(7)
+    ctx.close()
