@@ -180,6 +180,17 @@ DevRows rows_of(const rt_hip_ctx *c, const Batch &b)
     return R;
 }
 
+/* k_fold_deep takes the levels that hold at most this many nodes per shard (RT_HIP_DEEP_MAX in the
+ * environment; 0 = never) */
+uint32_t deep_entries()
+{
+    static const uint32_t v = [] {
+        const char *e = getenv("RT_HIP_DEEP_MAX");
+        return e && *e ? (uint32_t)strtoul(e, nullptr, 10) : 2048u;
+    }();
+    return v;
+}
+
 /* enqueue one image batch */
 int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
 {
@@ -205,7 +216,20 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
     const uint32_t depth = c->C.depth;
     for (uint32_t d = 1; d <= depth; ++d)
         rt_launch_bounce(c->S, c->C, Wk, d, stats, c->seen_valid ? (c->seen_hits[d] ? c->seen_hits[d] : 1u) : 0u, st);
-    for (uint32_t d = depth; d-- > 1;) /* nodes exist on levels 0..depth-1; level 0 folds in resolve */
+    /* Nodes exist on levels 0..depth-1; level 0 folds in resolve.  The sparse deep levels - from the
+     * first level on that the last batch of this shape left with few enough nodes per shard - fold in
+     * one launch, the others in one launch each. */
+    uint32_t fold_from = depth;
+    if (c->seen_valid && deep_entries() != 0u && depth >= 3u) {
+        uint32_t bottom = depth;
+        while (bottom > 1u && c->seen_nodes[bottom - 1u] <= deep_entries())
+            --bottom;
+        if (bottom + 1u < depth) { /* at least two levels */
+            rt_launch_fold_deep(Wk, depth - 1u, bottom, st);
+            fold_from = bottom;
+        }
+    }
+    for (uint32_t d = fold_from; d-- > 1;)
         rt_launch_fold(Wk, d, c->seen_valid ? (c->seen_nodes[d] ? c->seen_nodes[d] : 1u) : 0u, st);
     rt_launch_resolve(c->C, Wk, R, c->d_argb, c->d_rad, st);
     rt_launch_publish(Wk.counters, c->h_counters_dev + (size_t)b.slot * c->cwords, (uint32_t)c->cwords, st);

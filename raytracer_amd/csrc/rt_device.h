@@ -20,6 +20,7 @@
  * the intersection searches. */
 #define RT_PARK_WORDS   20u
 #define RT_PARK_FLOATS  (RT_PARK_WORDS * RT_BLOCK)
+#define RT_DEEP_SUB     4u          /* k_fold_deep: RT_BLOCK * RT_DEEP_SUB threads per block */
 
 /* Camera constants, pre-folded on the host with the reference's float rounding
  * (raytrace.c:737,751-768): everything that does not depend on the pixel. */
@@ -182,6 +183,7 @@ enum {
 static_assert(2 * ST_COUNT <= CNT_STATS_STRIDE, "statistics do not fit their line");
 
 /* launch wrappers implemented in rt_kernels.hip (all asynchronous on `stream`) */
+void rt_launch_fold_deep(const DevWork &Wk, uint32_t top_level, uint32_t bottom_level, hipStream_t stream);
 void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
                        bool stats, bool blinn, hipStream_t stream);
 /* `expect` = entries per shard the launch is expected to find (0 = unknown: a full resident set).

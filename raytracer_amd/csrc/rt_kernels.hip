@@ -1698,6 +1698,48 @@ __global__ __launch_bounds__(RT_BLOCK) void k_fold(DevWork Wk, uint32_t level)
     }
 }
 
+/*
+ * k_fold_deep: the folds of the sparse deep levels, top_level down to bottom_level, in ONE launch.
+ * A node's children are queued to, and made in, the shard of their parent, so a shard's trees never
+ * touch another shard's nodes: one block per shard folds level after level with nothing but a block
+ * barrier in between (what it reads was written by an earlier kernel, or by itself on its own CU).
+ * Each of those folds was a launch of ~5 us, nearly all of it latency.
+ */
+__global__ __launch_bounds__(RT_BLOCK * RT_DEEP_SUB) void k_fold_deep(DevWork Wk, uint32_t top_level, uint32_t bottom_level)
+{
+    uint32_t *cnt = Wk.counters;
+    if (overflowed_before(cnt))
+        return; /* raised by an earlier kernel: the same answer for every thread */
+    const uint32_t shard = blockIdx.x; /* one block per shard */
+    /* used_at[l] = nodes of this shard made on levels < l: one load per lane of the first wave, summed by thread 0 */
+    __shared__ uint32_t used_at[RT_MAX_LEVELS + 1];
+    if (threadIdx.x < RT_MAX_LEVELS)
+        used_at[threadIdx.x + 1u] = threadIdx.x <= top_level ? (uint32_t)*level_line(cnt, threadIdx.x, shard) : 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t sum = 0;
+        used_at[0] = 0;
+        for (uint32_t l = 1; l <= top_level + 1u; ++l) {
+            sum += used_at[l];
+            used_at[l] = min(sum, Wk.capS);
+        }
+    }
+    __syncthreads();
+    for (uint32_t level = top_level + 1u; level-- > bottom_level;) {
+        const uint32_t end = shard * Wk.capS + used_at[level + 1u];
+        for (uint32_t i = shard * Wk.capS + used_at[level] + threadIdx.x; i < end; i += RT_BLOCK * RT_DEEP_SUB) {
+            float c[3];
+            const uint32_t link = fold_node(Wk, i, c);
+            const uint32_t pn = link >> 3;
+            if (pn >= Wk.cap)
+                continue;
+            float4 *dst = (link & 1u) ? Wk.childT() : Wk.childR();
+            dst[pn] = make_float4(c[0], c[1], c[2], 0.0f);
+        }
+        __syncthreads(); /* the parents' slots are written before the level above reads them */
+    }
+}
+
 /* k_resolve: per pixel - fold this pixel's depth-0 roots, add them to the in-register sum of
  * the childless samples, scale (raytrace.c:779), store radiance, pack (raytrace.c:783-790). */
 __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DevCamera C, DevWork Wk, DevRows R,
@@ -1951,6 +1993,12 @@ void rt_launch_bounce(const DevScene &S, const DevCamera &C, const DevWork &Wk, 
                      : (stats ? k_bounce<false, true, false, 0> : k_bounce<false, false, false, 0>);
     const uint32_t grid = queue_grid(Wk, (const void *)kernel, lds, expect);
     kernel<<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, level);
+}
+
+/* folds of levels top_level .. bottom_level (top first) in one launch, one block per shard */
+void rt_launch_fold_deep(const DevWork &Wk, uint32_t top_level, uint32_t bottom_level, hipStream_t stream)
+{
+    k_fold_deep<<<RT_SHARDS, RT_BLOCK * RT_DEEP_SUB, 0, stream>>>(Wk, top_level, bottom_level);
 }
 
 void rt_launch_fold(const DevWork &Wk, uint32_t level, uint32_t expect, hipStream_t stream)

@@ -817,3 +817,29 @@ def test_second_shading_routine_is_bit_identical_and_counts_match(torch_cuda, ma
     with pytest.raises(rt.RtHipError):
         ctx.set_shading(7)
     ctx.close()
+
+
+@pytest.mark.parametrize("name,W,H,s,d", [("builtin", 640, 480, 2, 8), ("builtin", 333, 217, 3, 16),
+                                          ("syn64", 320, 240, 2, 6), ("syn3000", 192, 128, 2, 5)])
+def test_deep_folds_in_one_launch_change_nothing(torch_cuda, make_scene, name, W, H, s, d):
+    """The first render of a frame shape folds every level with a launch of its own; later renders on
+    the same context fold the sparse deep levels in one launch (k_fold_deep).  Same pixels, radiance
+    bits and counters."""
+    torch = torch_cuda
+    sc = make_scene(name)
+    cam = rt.prepare_camera(sc, W, H, s, d)
+    ctx = rt.Context()
+    ctx.upload(sc)
+    outs = []
+    for _ in range(3):
+        argb = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+        rad = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+        ctx.render_rows(cam, argb.data_ptr(), rad.data_ptr())
+        st = ctx.finish()
+        outs.append((argb, rad, (st.shade_nodes, st.reflection_rays, st.transmission_rays, st.tree_nodes,
+                                 st.queued_rays, st.overflow_retries)))
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0])
+        assert torch.equal(o[1].view(torch.int32), outs[0][1].view(torch.int32))
+        assert o[2] == outs[0][2]
+    ctx.close()
