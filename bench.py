@@ -133,6 +133,9 @@ def main():
     ap.add_argument("--overlap", action="store_true",
                     help="give every in-flight frame its own stream (kernels of neighbouring frames overlap; the "
                          "event-timed k_primary duration then includes the sharing and is not a clean roofline input)")
+    ap.add_argument("--tail-stream", choices=["on", "off"], default="on",
+                    help="enqueue the latency-bound tail of every frame (sparse deep levels, folds, resolve) on a "
+                         "second stream, so that it drains beside the next frame's k_primary (rt_hip_ctx_set_tail_stream)")
     ap.add_argument("--gather-stream", choices=["side", "same"], default="side",
                     help="N > 1: run the all-gather + de-interleave on a second stream behind events, so that they "
                          "overlap the next frame's render (default), or on the render stream (the frames then wait "
@@ -172,9 +175,12 @@ def main():
     inflight = max(1, args.inflight)
     ctxs, streams, gathers = [], [], []
     shared = torch.cuda.Stream(device=dev)
+    tail = torch.cuda.Stream(device=dev) if args.tail_stream == "on" and not args.overlap else None
     for _ in range(inflight):
         c = rt.Context(device=local_rank)
         c.upload(scene)
+        if tail is not None:
+            c.set_tail_stream(tail.cuda_stream)
         ctxs.append(c)
         streams.append(torch.cuda.Stream(device=dev) if args.overlap else shared)
         gathers.append(FrameGather(plan, W, torch.int32, dev, rank=rank))  # 0xFFRRGGBB bit patterns
@@ -196,7 +202,7 @@ def main():
             if i >= inflight:
                 st.wait_event(gathered[k])  # the previous gather out of this frame's buffers is done
             ctx.render_interleaved(cam, fg.local.data_ptr(), 0, rank, world, st.cuda_stream)
-            rendered[k].record(st)
+            rendered[k].record(tail if tail is not None else st)  # (the frame is complete on the tail stream)
         with torch.cuda.stream(comm):
             comm.wait_event(rendered[k])
             fg.gather(collective=not fake)  # in-place RCCL all-gather of the local slices + de-interleave
@@ -286,7 +292,7 @@ def main():
             "config": {"workload": f"builtin Whitted scene {W}x{H}, sqrtSpp {sqrt_spp} ({sqrt_spp * sqrt_spp} spp), "
                                    f"depth {depth}" + ("" if world == 1 else f", cyclic 8-row blocks over {world} GPUs + RCCL all-gather"),
                        "rays_per_step": rays_all / args.steps,
-                       "frames_in_flight": inflight, "streams": "one per frame" if args.overlap else "shared",
+                       "frames_in_flight": inflight, "streams": "one per frame" if args.overlap else ("shared + tail stream" if tail is not None else "shared"),
                        "parallelism": "1 GPU" if world == 1 else f"cyclic 8-row blocks over {world} GPUs"},
             "roofline": {"bound": "fp32_valu", "kernel": "k_primary", "achieved": achieved,
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,

@@ -271,6 +271,16 @@ int  rt_hip_render_stats(rt_hip_ctx *ctx, const rt_camera *camera,
 #define RT_SHADE_PHONGBLINN  1
 int  rt_hip_ctx_set_shading(rt_hip_ctx *ctx, int model);
 
+/* Optional second stream (a hipStream_t; NULL = none, the default) for the tail of every batch this
+ * context renders.  A batch of the reference's scene spends 0.29 ms in kernels that fill the GPU
+ * (k_primary, the first two bounce levels) and 0.14 ms in the sparse deep levels, the folds and the
+ * resolve, which are latency- and HBM-bound.  With a tail stream the second part is enqueued there
+ * behind an event, so a host that renders frame after frame (each frame in flight on a context of its
+ * own) gets the next frame's k_primary beside it.  The frame is then complete on the TAIL stream: order
+ * work that reads the pixels behind it, or call rt_hip_finish.  No counterpart in the reference (its
+ * frames are strictly sequential, main.c:159-165).  Pixels and counters are unchanged. */
+int  rt_hip_ctx_set_tail_stream(rt_hip_ctx *ctx, void *stream);
+
 /* Bracket the fused primary kernel with HIP events on the render stream (k0_ms). */
 void rt_hip_ctx_set_timing(rt_hip_ctx *ctx, int enable);
 /* Cap on primary samples per image batch (0 = automatic). */

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "librt_hip.so")  
 EXPORTS = [
     "raytrace", "rt_hip_render", "rt_camera_prepare", "rt_hip_ctx_create", "rt_hip_ctx_destroy",
     "rt_hip_scene_upload", "rt_hip_render_rows", "rt_hip_render_interleaved", "rt_hip_finish", "rt_hip_render_stats",
-    "rt_hip_ctx_set_timing", "rt_hip_ctx_set_batch_samples", "rt_hip_ctx_set_shading", "rt_hip_last_error", "rt_hip_version",
+    "rt_hip_ctx_set_timing", "rt_hip_ctx_set_batch_samples", "rt_hip_ctx_set_shading", "rt_hip_ctx_set_tail_stream", "rt_hip_last_error", "rt_hip_version",
     "rt_poly_plane", "rt_scene_builtin", "rt_parse_scene", "rt_scene_free", "rt_scene_synthetic",
     "rt_write_image", "write_image", "rt_hip_selftest_arith", "rt_load_scene", "rt_hip_deinterleave",
     "rt_hip_render_devices", "rt_hip_tone", "rt_hip_tone_sums", "rt_hip_tone_apply", "rt_hip_selftest_grid",
@@ -87,6 +87,8 @@ def load():
     lib.rt_hip_ctx_set_batch_samples.restype = None
     lib.rt_hip_ctx_set_shading.argtypes = [vp, i32]
     lib.rt_hip_ctx_set_shading.restype = i32
+    lib.rt_hip_ctx_set_tail_stream.argtypes = [vp, vp]
+    lib.rt_hip_ctx_set_tail_stream.restype = i32
     lib.rt_hip_last_error.restype = C.c_char_p
     lib.rt_hip_version.restype = C.c_char_p
     lib.rt_hip_selftest_arith.argtypes = [vp, vp, vp, u32, vp, vp, vp]

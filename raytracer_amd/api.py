@@ -161,6 +161,10 @@ class Context:
         get_shade_color_phongblinn, raytrace.c:574-685)"""
         check(load().rt_hip_ctx_set_shading(self._h, int(model)), "rt_hip_ctx_set_shading")
 
+    def set_tail_stream(self, stream):
+        """hipStream_t (int) for the latency-bound tail of every batch, 0 = none (rt_hip_ctx_set_tail_stream)"""
+        check(load().rt_hip_ctx_set_tail_stream(self._h, stream or None), "rt_hip_ctx_set_tail_stream")
+
     def set_batch_samples(self, n):
         load().rt_hip_ctx_set_batch_samples(self._h, int(n))
 

@@ -90,6 +90,11 @@ struct rt_hip_ctx {
     /* options */
     bool timing = false;
     int shading = RT_SHADE_PHONG;
+    /* optional second stream for the latency-bound tail of a batch (rt_hip_ctx_set_tail_stream) */
+    hipStream_t tail_stream = nullptr;
+    hipEvent_t head_done = nullptr, tail_done = nullptr;
+    bool tail_pending = false;  /* a tail of this context was enqueued and may still run         */
+    bool round_on_tail = false; /* the round in flight ends on the tail stream                    */
     uint64_t batch_samples = 0;
     std::vector<hipEvent_t> ev; /* 2 per batch when timing */
     hipEvent_t round_done = nullptr; /* recorded behind each round's counter copy: drain() waits for
@@ -180,6 +185,18 @@ DevRows rows_of(const rt_hip_ctx *c, const Batch &b)
     return R;
 }
 
+/* first level of a batch that goes to the tail stream (RT_HIP_TAIL_LEVEL in the environment, default 3:
+ * levels 1 and 2 of the reference's scene still fill the GPU) */
+uint32_t tail_level()
+{
+    static const uint32_t v = [] {
+        const char *e = getenv("RT_HIP_TAIL_LEVEL");
+        const uint32_t t = e && *e ? (uint32_t)strtoul(e, nullptr, 10) : 3u;
+        return t < 1u ? 1u : t;
+    }();
+    return v;
+}
+
 /* k_fold_deep takes the levels that hold at most this many nodes per shard (RT_HIP_DEEP_MAX in the
  * environment; 0 = never) */
 uint32_t deep_entries()
@@ -200,6 +217,14 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
     Wk.roots = c->roots;
     Wk.counters = c->d_counters + (size_t)b.slot * c->cwords;
     hipStream_t st = c->stream;
+    const uint32_t depth = c->C.depth;
+    /* With a tail stream the batch is cut behind the wide levels: k_primary and the bounces above
+     * tail_level() stay on the render stream, everything after them - the sparse levels, the folds, the
+     * resolve - goes to the tail stream behind an event, so that the render stream is free for the next
+     * frame's k_primary while this batch's latency-bound remainder (0.14 of its 0.43 ms) drains beside it. */
+    const uint32_t cut = (c->tail_stream && c->tail_stream != st && !stats && depth >= tail_level()) ? tail_level() : 0u;
+    if (cut && c->tail_pending) /* the queues and node pool are shared with this context's previous batch */
+        HIP_TRY(hipStreamWaitEvent(st, c->tail_done, 0));
     /* the counter block is zero: k_publish at the end of its last use left it so */
     const bool timed = c->timing && !stats;
     if (timed) {
@@ -213,9 +238,14 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
     rt_launch_primary(c->S, c->C, Wk, R, stats, c->shading == RT_SHADE_PHONGBLINN, st);
     if (timed)
         HIP_TRY(hipEventRecord(c->ev.back(), st));
-    const uint32_t depth = c->C.depth;
-    for (uint32_t d = 1; d <= depth; ++d)
+    for (uint32_t d = 1; d <= depth; ++d) {
+        if (d == cut) {
+            HIP_TRY(hipEventRecord(c->head_done, st));
+            st = c->tail_stream;
+            HIP_TRY(hipStreamWaitEvent(st, c->head_done, 0));
+        }
         rt_launch_bounce(c->S, c->C, Wk, d, stats, c->seen_valid ? (c->seen_hits[d] ? c->seen_hits[d] : 1u) : 0u, st);
+    }
     /* Nodes exist on levels 0..depth-1; level 0 folds in resolve.  The sparse deep levels - from the
      * first level on that the last batch of this shape left with few enough nodes per shard - fold in
      * one launch, the others in one launch each. */
@@ -233,6 +263,11 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
         rt_launch_fold(Wk, d, c->seen_valid ? (c->seen_nodes[d] ? c->seen_nodes[d] : 1u) : 0u, st);
     rt_launch_resolve(c->C, Wk, R, c->d_argb, c->d_rad, st);
     rt_launch_publish(Wk.counters, c->h_counters_dev + (size_t)b.slot * c->cwords, (uint32_t)c->cwords, st);
+    if (cut) {
+        HIP_TRY(hipEventRecord(c->tail_done, st));
+        c->tail_pending = true;
+        c->round_on_tail = true;
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -342,6 +377,7 @@ void accumulate(rt_hip_stats &s, const uint32_t *cnt, uint32_t levels)
 int enqueue_round(rt_hip_ctx *c)
 {
     c->batches.clear();
+    c->round_on_tail = false;
     while (!c->todo.empty() && c->batches.size() < kMaxBatches) {
         Batch b = c->todo.back();
         c->todo.pop_back();
@@ -354,7 +390,8 @@ int enqueue_round(rt_hip_ctx *c)
     if (!c->batches.empty()) { /* (each batch ended by publishing its counters to h_counters) */
         if (!c->round_done)
             HIP_TRY(hipEventCreateWithFlags(&c->round_done, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(c->round_done, c->stream));
+        /* (tails run in batch order on one stream: the last batch's tail ends the round) */
+        HIP_TRY(hipEventRecord(c->round_done, c->round_on_tail ? c->tail_stream : c->stream));
     }
     return 0;
 }
@@ -364,10 +401,14 @@ int enqueue_round(rt_hip_ctx *c)
 int drain(rt_hip_ctx *c)
 {
     for (;;) {
-        if (c->round_done && !c->batches.empty())
+        if (c->round_done && !c->batches.empty()) {
             HIP_TRY(hipEventSynchronize(c->round_done));
-        else
+        } else {
             HIP_TRY(hipStreamSynchronize(c->stream));
+            if (c->tail_pending)
+                HIP_TRY(hipStreamSynchronize(c->tail_stream));
+        }
+        c->tail_pending = false; /* (the round's last event covers every tail enqueued before it) */
         for (size_t i = 0; i < c->batches.size(); ++i) {
             const Batch &b = c->batches[i];
             const uint32_t *cnt = c->h_counters + i * c->cwords;
@@ -584,6 +625,8 @@ void rt_hip_ctx_destroy(rt_hip_ctx *c)
         (void)hipStreamSynchronize(c->stream);
     drop_events(c);
     if (c->round_done) (void)hipEventDestroy(c->round_done);
+    if (c->head_done) (void)hipEventDestroy(c->head_done);
+    if (c->tail_done) (void)hipEventDestroy(c->tail_done);
     if (c->scene_blob) (void)hipFree(c->scene_blob);
     if (c->work_blob) (void)hipFree(c->work_blob);
     if (c->pixAcc) (void)hipFree(c->pixAcc);
@@ -597,6 +640,25 @@ void rt_hip_ctx_set_timing(rt_hip_ctx *c, int enable)
 {
     if (c)
         c->timing = enable != 0;
+}
+
+int rt_hip_ctx_set_tail_stream(rt_hip_ctx *c, void *stream)
+{
+    if (!c) {
+        set_err("null argument");
+        return RT_E_INVALID;
+    }
+    int rc = ctx_set_device(c);
+    if (rc)
+        return rc;
+    if (c->pending && (rc = rt_hip_finish(c, nullptr))) /* the render in flight ends on the old stream */
+        return rc;
+    if (stream && !c->head_done) {
+        HIP_TRY(hipEventCreateWithFlags(&c->head_done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->tail_done, hipEventDisableTiming));
+    }
+    c->tail_stream = (hipStream_t)stream;
+    return 0;
 }
 
 int rt_hip_ctx_set_shading(rt_hip_ctx *c, int model)

@@ -22,8 +22,10 @@ def run_bench(args, env_extra=None):
     return json.loads(lines[0])
 
 
-def test_single_gpu_line_has_the_contract_fields():
-    d = run_bench(["--steps", "6", "--warmup", "2", "--no-cpu-baseline"])
+@pytest.mark.parametrize("tail", ["on", "off"])
+def test_single_gpu_line_has_the_contract_fields(tail):
+    d = run_bench(["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--tail-stream", tail])
+    assert d["config"]["streams"] == ("shared + tail stream" if tail == "on" else "shared")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in d, k
@@ -38,9 +40,9 @@ def test_single_gpu_line_has_the_contract_fields():
     assert d["value"] > 2e4 and abs(d["value"] - d["config"]["rays_per_step"] / d["ms_per_step"] / 1e3) < 1e-3 * d["value"]
 
 
-@pytest.mark.parametrize("gather", ["side", "same"])
-def test_rank_of_a_two_gpu_run_rehearsed_on_one_gpu(gather):
-    d = run_bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--gather-stream", gather],
+@pytest.mark.parametrize("gather,tail", [("side", "on"), ("same", "on"), ("side", "off")])
+def test_rank_of_a_two_gpu_run_rehearsed_on_one_gpu(gather, tail):
+    d = run_bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--gather-stream", gather, "--tail-stream", tail],
                   {"RT_BENCH_REHEARSE_WORLD": "2", "RT_BENCH_REHEARSE_RANK": "1"})
     assert d["n_gpus"] == 2 and "REHEARSAL" in d["data"]
     assert d["value"] > 1e4

@@ -843,3 +843,58 @@ def test_deep_folds_in_one_launch_change_nothing(torch_cuda, make_scene, name, W
         assert torch.equal(o[1].view(torch.int32), outs[0][1].view(torch.int32))
         assert o[2] == outs[0][2]
     ctx.close()
+
+
+def test_tail_stream_changes_nothing(torch_cuda, make_scene):
+    """rt_hip_ctx_set_tail_stream: the sparse levels, folds and resolve of every batch on a second stream.
+    Same pixels, radiance bits and counters as on one stream - for a single batch, for a frame cut into
+    many batches (a batch's head must wait for the previous batch's tail: they share the queues), with
+    two contexts alternating frames on the same pair of streams, and after switching it off again."""
+    torch = torch_cuda
+    sc = make_scene("builtin")
+    W, H, s, d = 640, 480, 2, 8
+    cam = rt.prepare_camera(sc, W, H, s, d)
+    main, tail = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def frame(ctx, stream=0):
+        argb = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+        rad = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        ctx.render_rows(cam, argb.data_ptr(), rad.data_ptr(), 0, H, stream)
+        return argb, rad
+
+    def counters(st):
+        return (st.shade_nodes, st.reflection_rays, st.transmission_rays, st.tree_nodes, st.queued_rays)
+
+    a, b = rt.Context(), rt.Context()
+    for c in (a, b):
+        c.upload(sc)
+    want_argb, want_rad = frame(a)
+    want = counters(a.finish())
+    for c in (a, b):
+        c.set_tail_stream(tail.cuda_stream)
+    # frames in flight on two contexts, the tails of one beside the heads of the other
+    pending = []
+    for i in range(6):
+        c = (a, b)[i % 2]
+        if i >= 2:
+            argb, rad = pending.pop(0)
+            assert counters(c.finish()) == want
+            assert torch.equal(argb, want_argb) and torch.equal(rad.view(torch.int32), want_rad.view(torch.int32))
+        pending.append(frame(c, main.cuda_stream))
+    for i, (argb, rad) in enumerate(pending):
+        assert counters((a, b)[i % 2].finish()) == want
+        assert torch.equal(argb, want_argb) and torch.equal(rad.view(torch.int32), want_rad.view(torch.int32))
+    # many batches per frame
+    a.set_batch_samples(W * 16 * s * s)
+    for _ in range(2):
+        argb, rad = frame(a, main.cuda_stream)
+        st = a.finish()
+        assert st.batches == H // 16 and counters(st) == want
+        assert torch.equal(argb, want_argb) and torch.equal(rad.view(torch.int32), want_rad.view(torch.int32))
+    a.set_batch_samples(0)
+    a.set_tail_stream(0)
+    argb, rad = frame(a, main.cuda_stream)
+    assert counters(a.finish()) == want and torch.equal(argb, want_argb)
+    a.close()
+    b.close()
