@@ -4,5 +4,5 @@
 tag=${1:-final}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py > gpurun_out/prof_$tag.log 2>&1 || exit 1
-tail -1 gpurun_out/prof_$tag.log > gpurun_out/bench_under_prof_$tag.json
+grep "^{" gpurun_out/prof_$tag.log > gpurun_out/bench_under_prof_$tag.json
 python3 tools/frame_timeline.py gpurun_out/prof_$tag
