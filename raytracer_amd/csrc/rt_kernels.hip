@@ -1937,7 +1937,11 @@ void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk,
         : rt_scene_shape(S) == 1 ? (stats ? k_primary<false, true, true, 1> : k_primary<false, false, true, 1>)
         : S.tabInLds ? (stats ? k_primary<false, true, true, 0> : k_primary<false, false, true, 0>)
                      : (stats ? k_primary<false, true, false, 0> : k_primary<false, false, false, 0>);
-    kernel<<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, R);
+    /* RT_HIP_PRIMARY_LDS=<bytes>: ask for at least that much LDS per block.  23600 leaves room for six
+     * blocks per CU instead of seven, i.e. a free block slot (LDS, 80 VGPRs) on every CU for the kernels of
+     * a tail stream, which otherwise get in only when a block of this kernel retires */
+    static const size_t pad_to = [] { const char *e = getenv("RT_HIP_PRIMARY_LDS"); return e ? (size_t)atol(e) : 0; }();
+    kernel<<<grid, RT_BLOCK, lds < pad_to && pad_to <= 65536 ? pad_to : lds, stream>>>(S, C, Wk, R);
 }
 
 /*
