@@ -621,8 +621,11 @@ void rt_hip_ctx_destroy(rt_hip_ctx *c)
     if (!c)
         return;
     (void)hipSetDevice(c->device);
-    if (c->pending)
+    if (c->pending) {
         (void)hipStreamSynchronize(c->stream);
+        if (c->tail_pending && c->tail_stream) /* (hipFree below would wait for it anyway) */
+            (void)hipStreamSynchronize(c->tail_stream);
+    }
     drop_events(c);
     if (c->round_done) (void)hipEventDestroy(c->round_done);
     if (c->head_done) (void)hipEventDestroy(c->head_done);

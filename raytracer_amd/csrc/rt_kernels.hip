@@ -1337,6 +1337,62 @@ __device__ __forceinline__ void primary_ray(const float *cam, float fu0, float f
     r.dx = r.dx * inv; r.dy = r.dy * inv; r.dz = r.dz * inv;
 }
 
+/*
+ * Can every sample of one pixel be shown to miss every object?  (Small scenes only: the test walks all
+ * spheres and planes.)  The samples' un-normalised directions lie within (|U| + |V|) * half a pixel of the
+ * pixel centre's (raytrace.c:751-771), so the unit directions d lie within eta of the centre's dc.
+ *   sphere  (ray.c:186-206) misses when B^2 - 4C < 0, i.e. when the centre's distance |e x d| to the line
+ *           exceeds r; |e x d| >= |e x dc| - |e| eta, and a margin of 1e-4 |e|^2 in the squares covers the
+ *           float error of either side (1e-6 relative);
+ *   polygon (ray.c:92-117) is rejected when w = -(n.o + F) / (n.d) < 0: numerator and denominator of
+ *           opposite, exactly known signs - n.d keeps the sign of n.dc when |n.dc| > |n| (eta + 1e-4),
+ *           and magnitudes far from underflow keep the quotient's sign.
+ * A pixel that passes contributes the background colour for every sample (raytrace.c:700-703), added
+ * spp^2 times in the reference's order.  Conservative: `false` just means "trace it".
+ */
+__device__ __forceinline__ bool pixel_sees_nothing(const DevScene &S, const float *cam, const float4 *lds_poly,
+                                                   const float4 *lds_sph, float fu0, float fv0, uint32_t sqrtSpp)
+{
+    const float half = 0.5f * (float)sqrtSpp * cam[CAM_SPPW];
+    const float fu = fu0 + half, fv = fv0 + half;
+    const float Dx = (cam[CAM_SHIFTN + 0] + cam[CAM_U + 0] * fu) + cam[CAM_V + 0] * fv;
+    const float Dy = (cam[CAM_SHIFTN + 1] + cam[CAM_U + 1] * fu) + cam[CAM_V + 1] * fv;
+    const float Dz = (cam[CAM_SHIFTN + 2] + cam[CAM_U + 2] * fu) + cam[CAM_V + 2] * fv;
+    const float D2 = dot3(Dx, Dy, Dz, Dx, Dy, Dz);
+    if (!(D2 > 1e-20f))
+        return false;
+    const float invD = 1.0f / sqrtf(D2);
+    const float dcx = Dx * invD, dcy = Dy * invD, dcz = Dz * invD;
+    const float lenU = sqrtf(dot3(cam[CAM_U + 0], cam[CAM_U + 1], cam[CAM_U + 2], cam[CAM_U + 0], cam[CAM_U + 1], cam[CAM_U + 2]));
+    const float lenV = sqrtf(dot3(cam[CAM_V + 0], cam[CAM_V + 1], cam[CAM_V + 2], cam[CAM_V + 0], cam[CAM_V + 1], cam[CAM_V + 2]));
+    /* |d - dc| <= |D - Dc| / |Dc| for unit vectors made from D, Dc (times 1 / (1 - x/2) <= 1.13 for the x < 0.22 admitted below) */
+    const float eta = 1.15f * ((lenU + lenV) * fabsf(half)) * invD + 1e-6f;
+    if (!(eta < 0.25f))
+        return false;
+    const float ox = cam[CAM_EYE + 0], oy = cam[CAM_EYE + 1], oz = cam[CAM_EYE + 2];
+    for (uint32_t k = 0; k < S.nSph; ++k) {
+        const float4 sp = lds_sph[k]; /* (centre, r^2) */
+        const float ex = ox - sp.x, ey = oy - sp.y, ez = oz - sp.z;
+        const float e2 = dot3(ex, ey, ez, ex, ey, ez);
+        const float t = dot3(ex, ey, ez, dcx, dcy, dcz);
+        const float rho = sqrtf(fmaxf(e2 - t * t, 0.0f));
+        const float m = rho - sqrtf(e2) * eta;
+        if (!(m > 0.0f && m * m > sp.w + 1e-4f * e2 + 1e-30f))
+            return false;
+    }
+    for (uint32_t k = 0; k < S.nPoly; ++k) {
+        const float4 pl = lds_poly[k]; /* (A, B, C, F) */
+        const float num = -1.0f * (dot3(pl.x, pl.y, pl.z, ox, oy, oz) + pl.w);
+        const float q = dot3(pl.x, pl.y, pl.z, dcx, dcy, dcz);
+        const float nlen = sqrtf(dot3(pl.x, pl.y, pl.z, pl.x, pl.y, pl.z));
+        const bool behind = fabsf(q) > nlen * (eta + 1e-4f) && fabsf(q) < 1e10f && fabsf(num) > 1e-20f &&
+                            fabsf(num) < 1e10f && ((num > 0.0f) != (q > 0.0f));
+        if (!behind)
+            return false;
+    }
+    return true;
+}
+
 /* Where shade_and_spawn gets the eye ray back from after the shadow rays (see there).  The empty
  * asm makes the input opaque, so the compiler cannot fold the rebuild / re-read into the first
  * one and keep the values in registers across the any-hit searches after all. */
@@ -1482,6 +1538,23 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
     SpawnCounts sc;
     Tally<STATS> tl;
     PhaseClock pc; /* unused here */
+
+    /* A tile none of whose pixels can see anything (sky: 40 % of the tiles of the reference's scene) is
+     * finished without tracing: spp^2 times the background colour, added in the reference's order.  The
+     * instrumented kernels trace everything (they count the reference's tests). */
+    if constexpr (!GRID && !STATS) {
+        const bool nothing = !valid || pixel_sees_nothing(S, cam, lds_poly, lds_sph, fu0, fv0, C.sqrtSpp);
+        if (__all(nothing)) { /* wave-uniform; no barrier follows */
+            for (uint32_t k = 0; k < C.sqrtSpp * C.sqrtSpp; ++k) {
+                accr = accr + kc[KC_BG + 0];
+                accg = accg + kc[KC_BG + 1];
+                accb = accb + kc[KC_BG + 2];
+            }
+            if (valid)
+                Wk.pixAcc[pix] = make_float4(accr, accg, accb, __uint_as_float(0u));
+            return;
+        }
+    }
 
     for (uint32_t j = 0; j < C.sqrtSpp; ++j) {
         for (uint32_t i = 0; i < C.sqrtSpp; ++i) {
