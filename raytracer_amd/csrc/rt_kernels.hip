@@ -1338,8 +1338,8 @@ __device__ __forceinline__ void primary_ray(const float *cam, float fu0, float f
 }
 
 /*
- * Can every sample of one pixel be shown to miss every object?  (Small scenes only: the test walks all
- * spheres and planes.)  The samples' un-normalised directions lie within (|U| + |V|) * half a pixel of the
+ * Can every sample of one pixel be shown to miss every object?  (Small scenes walk all spheres; big ones
+ * test the ball around their grid.)  The samples' un-normalised directions lie within (|U| + |V|) * half a pixel of the
  * pixel centre's (raytrace.c:751-771), so the unit directions d lie within eta of the centre's dc.
  *   sphere  (ray.c:186-206) misses when B^2 - 4C < 0, i.e. when the centre's distance |e x d| to the line
  *           exceeds r; |e x d| >= |e x dc| - |e| eta, and a margin of 1e-4 |e|^2 in the squares covers the
@@ -1350,6 +1350,7 @@ __device__ __forceinline__ void primary_ray(const float *cam, float fu0, float f
  * A pixel that passes contributes the background colour for every sample (raytrace.c:700-703), added
  * spp^2 times in the reference's order.  Conservative: `false` just means "trace it".
  */
+template <bool GRID>
 __device__ __forceinline__ bool pixel_sees_nothing(const DevScene &S, const float *cam, const float4 *lds_poly,
                                                    const float4 *lds_sph, float fu0, float fv0, uint32_t sqrtSpp)
 {
@@ -1370,7 +1371,23 @@ __device__ __forceinline__ bool pixel_sees_nothing(const DevScene &S, const floa
     if (!(eta < 0.25f))
         return false;
     const float ox = cam[CAM_EYE + 0], oy = cam[CAM_EYE + 1], oz = cam[CAM_EYE + 2];
-    for (uint32_t k = 0; k < S.nSph; ++k) {
+    if constexpr (GRID) {
+        /* Big scenes: one test against the ball around the grid's box, which holds every sphere whole.  A
+         * line that misses the ball by delta misses sphere k by delta as well, but for a small sphere
+         * rho^2 - r^2 >= delta^2 is all that is left of the margin: delta >= 5e-3 (|e| + R) keeps it at
+         * 2.5e-5 |e_k|^2, six times the float error of the reference's discriminant. */
+        const GridHeader &G = *(const GridHeader *)S.grid;
+        const float bx = G.gmax[0] - G.gmin[0], by = G.gmax[1] - G.gmin[1], bz = G.gmax[2] - G.gmin[2];
+        const float R = 0.5f * sqrtf(dot3(bx, by, bz, bx, by, bz)) * 1.001f;
+        const float ex = ox - G.centre[0], ey = oy - G.centre[1], ez = oz - G.centre[2];
+        const float e2 = dot3(ex, ey, ez, ex, ey, ez);
+        const float t = dot3(ex, ey, ez, dcx, dcy, dcz);
+        const float E = sqrtf(e2);
+        const float m = sqrtf(fmaxf(e2 - t * t, 0.0f)) - E * eta;
+        if (!(m > R + 5e-3f * (E + R)))
+            return false;
+    }
+    for (uint32_t k = 0; k < (GRID ? 0u : S.nSph); ++k) {
         const float4 sp = lds_sph[k]; /* (centre, r^2) */
         const float ex = ox - sp.x, ey = oy - sp.y, ez = oz - sp.z;
         const float e2 = dot3(ex, ey, ez, ex, ey, ez);
@@ -1542,8 +1559,8 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
     /* A tile none of whose pixels can see anything (sky: 40 % of the tiles of the reference's scene) is
      * finished without tracing: spp^2 times the background colour, added in the reference's order.  The
      * instrumented kernels trace everything (they count the reference's tests). */
-    if constexpr (!GRID && !STATS) {
-        const bool nothing = !valid || pixel_sees_nothing(S, cam, lds_poly, lds_sph, fu0, fv0, C.sqrtSpp);
+    if constexpr (!STATS) {
+        const bool nothing = !valid || pixel_sees_nothing<GRID>(S, cam, lds_poly, lds_sph, fu0, fv0, C.sqrtSpp);
         if (__all(nothing)) { /* wave-uniform; no barrier follows */
             for (uint32_t k = 0; k < C.sqrtSpp * C.sqrtSpp; ++k) {
                 accr = accr + kc[KC_BG + 0];
