@@ -185,16 +185,18 @@ DevRows rows_of(const rt_hip_ctx *c, const Batch &b)
     return R;
 }
 
-/* first level of a batch that goes to the tail stream (RT_HIP_TAIL_LEVEL in the environment, default 3:
- * levels 1 and 2 of the reference's scene still fill the GPU) */
-uint32_t tail_level()
+/* First level of a batch that goes to the tail stream: RT_HIP_TAIL_LEVEL in the environment, default 3
+ * (levels 1 and 2 of the reference's scene still fill the GPU; 4 is 0.8 % better there, 2 and 5 worse; a
+ * rule from the last batch's level sizes - "fewer entries than one block per CU" - picked worse: 0.358
+ * against 0.344 ms).  depth + 1 = only the folds and the resolve. */
+uint32_t tail_level(uint32_t depth)
 {
-    static const uint32_t v = [] {
+    static const uint32_t fixed = [] {
         const char *e = getenv("RT_HIP_TAIL_LEVEL");
         const uint32_t t = e && *e ? (uint32_t)strtoul(e, nullptr, 10) : 3u;
         return t < 1u ? 1u : t;
     }();
-    return v;
+    return fixed > depth + 1u ? depth + 1u : fixed;
 }
 
 /* k_fold_deep takes the levels that hold at most this many nodes per shard (RT_HIP_DEEP_MAX in the
@@ -222,7 +224,7 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
      * tail_level() stay on the render stream, everything after them - the sparse levels, the folds, the
      * resolve - goes to the tail stream behind an event, so that the render stream is free for the next
      * frame's k_primary while this batch's latency-bound remainder (0.14 of its 0.43 ms) drains beside it. */
-    const uint32_t cut = (c->tail_stream && c->tail_stream != st && !stats && depth >= tail_level()) ? tail_level() : 0u;
+    const uint32_t cut = (c->tail_stream && c->tail_stream != st && !stats) ? tail_level(depth) : 0u;
     if (cut && c->tail_pending) /* the queues and node pool are shared with this context's previous batch */
         HIP_TRY(hipStreamWaitEvent(st, c->tail_done, 0));
     /* the counter block is zero: k_publish at the end of its last use left it so */
@@ -238,13 +240,24 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
     rt_launch_primary(c->S, c->C, Wk, R, stats, c->shading == RT_SHADE_PHONGBLINN, st);
     if (timed)
         HIP_TRY(hipEventRecord(c->ev.back(), st));
+    auto to_tail = [&]() -> int {
+        HIP_TRY(hipEventRecord(c->head_done, st));
+        st = c->tail_stream;
+        HIP_TRY(hipStreamWaitEvent(st, c->head_done, 0));
+        return 0;
+    };
     for (uint32_t d = 1; d <= depth; ++d) {
         if (d == cut) {
-            HIP_TRY(hipEventRecord(c->head_done, st));
-            st = c->tail_stream;
-            HIP_TRY(hipStreamWaitEvent(st, c->head_done, 0));
+            const int rc = to_tail();
+            if (rc)
+                return rc;
         }
         rt_launch_bounce(c->S, c->C, Wk, d, stats, c->seen_valid ? (c->seen_hits[d] ? c->seen_hits[d] : 1u) : 0u, st);
+    }
+    if (cut == depth + 1u) {
+        const int rc = to_tail();
+        if (rc)
+            return rc;
     }
     /* Nodes exist on levels 0..depth-1; level 0 folds in resolve.  The sparse deep levels - from the
      * first level on that the last batch of this shape left with few enough nodes per shard - fold in
