@@ -898,3 +898,30 @@ def test_tail_stream_changes_nothing(torch_cuda, make_scene):
     assert counters(a.finish()) == want and torch.equal(argb, want_argb)
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("depth,shading", [(0, rt.SHADE_PHONG), (1, rt.SHADE_PHONG), (2, rt.SHADE_PHONG),
+                                           (8, rt.SHADE_PHONGBLINN)])
+def test_tail_stream_on_shallow_frames(torch_cuda, make_scene, depth, shading):
+    """Frames with fewer levels than the cut keep only folds and resolve on the tail stream."""
+    torch = torch_cuda
+    sc = make_scene("builtin")
+    W, H, s = 320, 240, 2
+    cam = rt.prepare_camera(sc, W, H, s, depth)
+    main, tail = torch.cuda.Stream(), torch.cuda.Stream()
+    ctx = rt.Context()
+    ctx.upload(sc)
+    ctx.set_shading(shading)
+    outs = []
+    for use_tail in (False, True, True):
+        ctx.set_tail_stream(tail.cuda_stream if use_tail else 0)
+        argb = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+        rad = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        ctx.render_rows(cam, argb.data_ptr(), rad.data_ptr(), 0, H, main.cuda_stream)
+        st = ctx.finish()
+        outs.append((argb, rad, (st.shade_nodes, st.reflection_rays, st.transmission_rays, st.tree_nodes)))
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1].view(torch.int32), outs[0][1].view(torch.int32))
+        assert o[2] == outs[0][2]
+    ctx.close()
