@@ -240,19 +240,21 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    k0_ms, k0_n, rays_rank = 0.0, 0, 0
+    k0_ms, k0_n, rays_rank, shadow_rank = 0.0, 0, 0, 0
     for i in range(args.steps):
         if i >= inflight:
             st = collect(i - inflight)
             k0_ms += st.k0_ms
             k0_n += st.k0_launches
             rays_rank += (st.primary_rays + st.shadow_rays + st.reflection_rays + st.transmission_rays)
+            shadow_rank += st.shadow_rays
         submit(i)
     for i in range(max(0, args.steps - inflight), args.steps):
         st = collect(i)
         k0_ms += st.k0_ms
         k0_n += st.k0_launches
         rays_rank += (st.primary_rays + st.shadow_rays + st.reflection_rays + st.transmission_rays)
+        shadow_rank += st.shadow_rays
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -260,14 +262,14 @@ def main():
     for c in ctxs:
         c.set_timing(False)
 
-    tot = torch.tensor([dt, float(rays_rank)], dtype=torch.float64, device=dev)
+    tot = torch.tensor([dt, float(rays_rank), float(shadow_rank)], dtype=torch.float64, device=dev)
     if dist is not None:
         tmax = tot.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dt_max, rays_all = float(tmax[0]), float(tot[1])
+        dt_max, rays_all, shadow_all = float(tmax[0]), float(tot[1]), float(tot[2])
     else:
-        dt_max, rays_all = dt, float(rays_rank)
+        dt_max, rays_all, shadow_all = dt, float(rays_rank), float(shadow_rank)
 
     if rank == 0 or fake:  # (a rehearsal prints whichever rank it plays)
         samples = W * my_rows * sqrt_spp * sqrt_spp
@@ -292,6 +294,9 @@ def main():
             "config": {"workload": f"builtin Whitted scene {W}x{H}, sqrtSpp {sqrt_spp} ({sqrt_spp * sqrt_spp} spp), "
                                    f"depth {depth}" + ("" if world == 1 else f", cyclic 8-row blocks over {world} GPUs + RCCL all-gather"),
                        "rays_per_step": rays_all / args.steps,
+                       # the sub-total without shadow rays, and its rate
+                       "rays_per_step_without_shadow": (rays_all - shadow_all) / args.steps,
+                       "mrays_per_s_without_shadow": (rays_all - shadow_all) / dt_max / 1e6,
                        "frames_in_flight": inflight, "streams": "one per frame" if args.overlap else ("shared + tail stream" if tail is not None else "shared"),
                        "parallelism": "1 GPU" if world == 1 else f"cyclic 8-row blocks over {world} GPUs"},
             "roofline": {"bound": "fp32_valu", "kernel": "k_primary", "achieved": achieved,
