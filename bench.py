@@ -73,6 +73,19 @@ def measured_traffic(W, H, sqrt_spp, depth):
     return t["k_primary"]["bytes_per_launch"]
 
 
+def executed_lane_ops(W, H, sqrt_spp, depth):
+    """SURVEY 8(d) asks for "executed" next to "algorithmic": vector lane operations k_primary really issues
+    per launch (SQ_INSTS_VALU x 64 from the committed PMC pass), same workload condition as above."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+    except OSError:
+        return None
+    w = t["workload"]
+    if (w["W"], w["H"], w["sqrt_spp"], w["depth"]) != (W, H, sqrt_spp, depth):
+        return None
+    return t["k_primary"].get("executed_valu_lane_ops_per_launch")
+
+
 def cpu_all_cores(O, sc, W, H, sqrt_spp, depth):
     """the oracle port with its row-parallel OpenMP loop on the host cores this job
     may use (OMP_NUM_THREADS on the GPU box, else the CPU count, at most 16), two full frames."""
@@ -304,6 +317,7 @@ def main():
                          "traffic": measured_traffic(W, H, sqrt_spp, depth) if world == 1 else None,
                          "traffic_unit": "bytes per launch (PMC, profiles/r01_traffic.json)",
                          "algorithmic_flop_per_launch": flops_k0 / max(launches_per_step, 1),
+                         "executed_valu_lane_ops_per_launch": executed_lane_ops(W, H, sqrt_spp, depth) if world == 1 else None,
                          "avg_launch_ms": k0_avg_ms},
         }
         # the secondary bound, HBM, from the measured bytes of the same kernel
