@@ -506,7 +506,8 @@ int rt_load_scene(const char *filename, rt_scene_t *scene)
             scene->nObjects = i + 1; /* what rt_scene_free must walk if a later allocation fails */
         }
         if (ok) {
-            memcpy(scene->lights, lights, nlight * sizeof *lights);
+            if (nlight) /* (a scene without lights has no array to copy from) */
+                memcpy(scene->lights, lights, nlight * sizeof *lights);
             scene->nLights = nlight;
         }
     }
