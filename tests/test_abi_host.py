@@ -266,3 +266,14 @@ def test_command_line_host_keeps_the_reference_messages(tmp_path):
     assert "Running Ray Tracer...\n" in p.stdout and p.stdout.endswith("Error parsing scene file.  Exiting...\n")
     p = subprocess.run([exe, "o.ppm", "scene", "8", "8", "1", "1", "--frobnicate"], capture_output=True, text=True)
     assert p.returncode == 1 and "unknown option" in p.stdout
+
+
+def test_scene_loader_under_sanitizers_on_mutated_files():
+    """rt_load_scene compiled with gcc -fsanitize=address,undefined on 300 mutated scene files
+    (tools/fuzz_loader.py): no finding, whatever the file says."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_loader.py"), "300", "7"], capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "300 files, 0 batches with findings" in p.stdout
