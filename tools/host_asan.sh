@@ -1,7 +1,8 @@
 #!/bin/bash
 # development: build librt_hip with AddressSanitizer + UBSan on the HOST code only (device code as shipped) and the
 # driver tools/host_asan_driver.c against it, into tools/asan_out/ (CPU, here); run tools/asan_out/driver on the GPU box
-# with ASAN_OPTIONS=verify_asan_link_order=0:detect_leaks=0 LD_LIBRARY_PATH=tools/asan_out.
+# with ASAN_OPTIONS=verify_asan_link_order=0:detect_leaks=0:protect_shadow_gap=0 (take tools/asan_out out of
+# .gpurunignore for that call: it is listed there so that ordinary calls do not upload 12 MB of sanitizer builds).
 set -e
 cd "$(dirname "$0")/.."
 S=raytracer_amd/csrc; O=tools/asan_out; mkdir -p $O
