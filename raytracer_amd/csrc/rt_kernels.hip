@@ -857,6 +857,26 @@ __device__ __forceinline__ unsigned long long *level_line(uint32_t *counters, ui
     return (unsigned long long *)(counters + CNT_LEVELS + (level * RT_SHARDS + shard) * RT_LINE_WORDS);
 }
 
+/* What a shard has made so far, in ONE memory round trip: lane l of the calling wave loads the counter
+ * line of level l (every lane must be active), the sums are taken over lanes.  The loop of scalar
+ * loads it replaces, one per level and each waited for, cost 3 us per frame (0.4068 -> 0.4038 ms).
+ *   used  = nodes made on levels < level (first node index of `level` in the shard's range)
+ *   nodes = nodes made on `level` itself (final once the kernel that processes `level` has ended)
+ *   hits  = hits queued for `level` (by the kernel that processed level - 1; 0 for level 0)          */
+struct LevelCounts { uint32_t used, nodes, hits; };
+__device__ __forceinline__ LevelCounts level_counts(uint32_t *counters, uint32_t level, uint32_t shard)
+{
+    const unsigned long long line = *level_line(counters, min(lane_id(), level), shard);
+    const uint32_t lo = (uint32_t)line, hi = (uint32_t)(line >> 32);
+    LevelCounts c;
+    c.used = 0;
+    for (uint32_t l = 0; l < level; ++l)
+        c.used += (uint32_t)__builtin_amdgcn_readlane((int)lo, (int)l);
+    c.nodes = (uint32_t)__builtin_amdgcn_readlane((int)lo, (int)level);
+    c.hits = level ? (uint32_t)__builtin_amdgcn_readlane((int)hi, (int)(level - 1u)) : 0u;
+    return c;
+}
+
 /* Did any kernel of this batch overflow a queue or a node range?  The batch is abandoned then (the
  * host renders it again in smaller pieces) and every later kernel returns at once: its inputs hold
  * unwritten slots.  The kernels that could have raised the flag have finished, so the answer is the
@@ -1645,9 +1665,10 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_BOUNCE1 : RT_WPE)) v
     const uint32_t shard = blockIdx.x % RT_SHARDS;
     const uint32_t slice = blockIdx.x / RT_SHARDS, nslices = gridDim.x / RT_SHARDS;
     uint32_t *cnt = Wk.counters;
+    const LevelCounts lc = level_counts(cnt, level, shard); /* (issued before the flag is waited for) */
     if (overflowed_before(cnt))
         return; /* the batch is being abandoned: its queues hold unwritten slots */
-    const uint32_t n = min((uint32_t)(*level_line(cnt, level - 1, shard) >> 32), Wk.capS);
+    const uint32_t n = min(lc.hits, Wk.capS);
     if (slice * RT_BLOCK >= n)
         return; /* block-uniform */
 
@@ -1663,10 +1684,7 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_BOUNCE1 : RT_WPE)) v
     __syncthreads();
 
     /* first node index of this level in this shard = nodes made by all shallower levels */
-    uint32_t used = 0;
-    for (uint32_t l = 0; l < level; ++l)
-        used += (uint32_t)*level_line(cnt, l, shard);
-    used = min(used, Wk.capS);
+    const uint32_t used = min(lc.used, Wk.capS);
     const uint32_t node_base = shard * Wk.capS + used;
     const uint32_t node_room = Wk.capS - used;
     const uint32_t qbase = shard * Wk.capS;
@@ -1767,16 +1785,14 @@ __device__ __forceinline__ uint32_t fold_node(const DevWork &Wk, uint32_t i, flo
 __global__ __launch_bounds__(RT_BLOCK) void k_fold(DevWork Wk, uint32_t level)
 {
     uint32_t *cnt = Wk.counters;
-    if (overflowed_before(cnt))
-        return;
     const uint32_t shard = blockIdx.x % RT_SHARDS;
     const uint32_t slice = blockIdx.x / RT_SHARDS, nslices = gridDim.x / RT_SHARDS;
-    uint32_t used = 0;
-    for (uint32_t l = 0; l < level; ++l)
-        used += (uint32_t)*level_line(cnt, l, shard);
-    used = min(used, Wk.capS);
+    const LevelCounts lc = level_counts(cnt, level, shard);
+    if (overflowed_before(cnt))
+        return;
+    const uint32_t used = min(lc.used, Wk.capS);
     const uint32_t start = shard * Wk.capS + used;
-    const uint32_t end = start + min((uint32_t)*level_line(cnt, level, shard), Wk.capS - used);
+    const uint32_t end = start + min(lc.nodes, Wk.capS - used);
     for (uint32_t i = start + slice * RT_BLOCK + threadIdx.x; i < end; i += nslices * RT_BLOCK) {
         float c[3];
         const uint32_t link = fold_node(Wk, i, c);
