@@ -925,3 +925,35 @@ def test_tail_stream_on_shallow_frames(torch_cuda, make_scene, depth, shading):
         assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1].view(torch.int32), outs[0][1].view(torch.int32))
         assert o[2] == outs[0][2]
     ctx.close()
+
+
+def test_tail_stream_with_small_queues_and_overflow_retries(torch_cuda, make_scene):
+    """Small queues: the frame is cut into batches, some overflow and are rendered again in halves - with
+    every batch's tail on the second stream.  Same pixels as one stream with default queues."""
+    torch = torch_cuda
+    sc = make_scene("builtin")
+    W, H, s, d = 640, 480, 2, 8
+    cam = rt.prepare_camera(sc, W, H, s, d)
+    main, tail = torch.cuda.Stream(), torch.cuda.Stream()
+    ref = rt.Context()
+    ref.upload(sc)
+    want = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    want_rad = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    ref.render_rows(cam, want.data_ptr(), want_rad.data_ptr())
+    st0 = ref.finish()
+    ref.close()
+    small = rt.Context(queue_cap=1 << 19)
+    small.upload(sc)
+    small.set_tail_stream(tail.cuda_stream)
+    retries = 0
+    for _ in range(3):
+        argb = torch.zeros_like(want)
+        rad = torch.zeros_like(want_rad)
+        torch.cuda.synchronize()
+        small.render_rows(cam, argb.data_ptr(), rad.data_ptr(), 0, H, main.cuda_stream)
+        st = small.finish()
+        retries += st.overflow_retries
+        assert st.batches > 1
+        assert (st.shade_nodes, st.tree_nodes, st.queued_rays) == (st0.shade_nodes, st0.tree_nodes, st0.queued_rays)
+        assert torch.equal(argb, want) and torch.equal(rad.view(torch.int32), want_rad.view(torch.int32))
+    small.close()
