@@ -5,6 +5,7 @@
  */
 #include "rt_device.h"
 #include "rt_hip.h"
+#include "rt_internal.h"
 
 #include <cmath>
 #include <mutex>
@@ -18,13 +19,7 @@ namespace {
 
 thread_local char g_err[512] = "";
 
-void set_err(const char *fmt, ...)
-{
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof g_err, fmt, ap);
-    va_end(ap);
-}
+#define set_err rt_set_err
 
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
@@ -56,6 +51,14 @@ struct Job {
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 } // namespace
+
+void rt_set_err(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
 
 struct rt_hip_ctx {
     int device = 0;
@@ -925,10 +928,10 @@ int rt_hip_scene_upload(rt_hip_ctx *c, const rt_scene *sc)
     int rc = ctx_set_device(c);
     if (rc)
         return rc;
-    if (c->pending) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        c->pending = false;
-    }
+    /* a render still in flight reads the old scene: finish it properly - overflow retries drained, the
+     * tail stream waited for, counters collected - before its blob may be replaced */
+    if (c->pending && (rc = rt_hip_finish(c, nullptr)))
+        return rc;
 
     const uint32_t nObj = sc->nObjects, nL = sc->nLights;
     std::vector<float4> sph, planes, infos, verts, edges;
@@ -1290,6 +1293,20 @@ int rt_hip_render(const rt_scene *scene, const rt_camera *cam, rt_framebuffer *f
     }
     std::lock_guard<std::mutex> lk(g_mu);
     int rc;
+    /* "the current HIP device": the cached context and frame buffers follow the caller when it has
+     * switched devices since the last call */
+    int current = 0;
+    HIP_TRY(hipGetDevice(&current));
+    if (g_ctx && g_ctx->device != current) {
+        (void)hipSetDevice(g_ctx->device);
+        rt_hip_ctx_destroy(g_ctx);
+        g_ctx = nullptr;
+        if (g_argb) (void)hipFree(g_argb);
+        if (g_rad) (void)hipFree(g_rad);
+        g_argb = nullptr; g_rad = nullptr;
+        g_argb_px = g_rad_px = 0;
+        HIP_TRY(hipSetDevice(current));
+    }
     /* queue capacity sized to the job: 2 entries per primary sample, 1 Mi .. default */
     const uint64_t samples = (uint64_t)fb->width * fb->nrows * cam->sqrtSpp * cam->sqrtSpp;
     uint64_t want = samples * 2 < (1ull << 20) ? (1ull << 20) : samples * 2;
@@ -1408,6 +1425,10 @@ int rt_hip_render_devices(const rt_scene *scene, const rt_camera *cam, rt_frameb
     std::lock_guard<std::mutex> lk(g_mu);
     int before = 0;
     HIP_TRY(hipGetDevice(&before));
+    struct Restore { /* the caller's current device comes back on every exit path */
+        int device;
+        ~Restore() { (void)hipSetDevice(device); }
+    } restore{before};
     const uint32_t W = fb->width, H = fb->height, n = ndevices;
     const uint32_t nblocks = (H + 7u) / 8u, per = (nblocks + n - 1u) / n;
     const size_t local_px = (size_t)per * 8u * W;
@@ -1494,7 +1515,6 @@ int rt_hip_render_devices(const rt_scene *scene, const rt_camera *cam, rt_frameb
                     scatter_blocks(fb->radiance, g_slots[r].h_rad, 3 * sizeof(float), W, H, r, n);
             }
         }
-    (void)hipSetDevice(before);
     return rc;
 }
 

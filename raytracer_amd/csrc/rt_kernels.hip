@@ -30,6 +30,7 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <mutex>
 
 #ifndef RT_SPHERES_PER_TRIP
 #define RT_SPHERES_PER_TRIP 8u
@@ -2059,11 +2060,14 @@ void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk,
 static uint32_t queue_grid(const DevWork &Wk, const void *kernel, size_t lds, uint32_t expect)
 {
     struct Entry { const void *kernel; size_t lds; int device; uint32_t blocks; };
-    static Entry cache[16];
+    constexpr int kCache = 256; /* devices x kernel variants x LDS sizes */
+    static Entry cache[kCache];
     static int ncache = 0;
+    static std::mutex mu; /* contexts launch from several threads */
     int device = 0;
     (void)hipGetDevice(&device);
     uint32_t resident = 0;
+    std::lock_guard<std::mutex> lk(mu);
     for (int i = 0; i < ncache; ++i)
         if (cache[i].kernel == kernel && cache[i].lds == lds && cache[i].device == device)
             resident = cache[i].blocks;
@@ -2074,7 +2078,7 @@ static uint32_t queue_grid(const DevWork &Wk, const void *kernel, size_t lds, ui
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1)
             cus = 256;
         resident = (uint32_t)per_cu * (uint32_t)cus;
-        if (ncache < 16)
+        if (ncache < kCache)
             cache[ncache++] = {kernel, lds, device, resident};
     }
     uint32_t slices = resident / RT_SHARDS;

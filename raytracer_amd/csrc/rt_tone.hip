@@ -21,13 +21,15 @@
  */
 #include "rt_device.h"
 #include "rt_hip.h"
+#include "rt_internal.h"
 
 #include <hip/hip_runtime.h>
 #include <mutex>
 
-namespace {
-
 constexpr uint32_t kToneBlocks = 1024; /* partial sums per launch */
+constexpr size_t kScratchDoubles = 2 * kToneBlocks + 4; /* 2 * kToneBlocks partials, then 3 sums (+1 pad) */
+
+namespace {
 
 __device__ __forceinline__ float luminance(float r, float g, float b)
 {
@@ -145,21 +147,39 @@ __global__ __launch_bounds__(RT_BLOCK) void k_tone_apply(float *radiance, uint32
 
 /* per-device scratch of the convenience entry points: partial sums + the three sums */
 struct ToneScratch {
-    double *partial = nullptr; /* 2 * kToneBlocks, then 3 sums */
+    double *partial = nullptr; /* hipMalloc'd on first use: rt_hip_tone, rt_hip_tone_sums */
 };
 std::mutex g_tone_mu;
 ToneScratch g_tone[64];
 
+
+int current_device(int *dev)
+{
+    const hipError_t e = hipGetDevice(dev);
+    if (e != hipSuccess) {
+        rt_set_err("hipGetDevice failed: %s", hipGetErrorString(e));
+        return -(int)e;
+    }
+    if (*dev < 0 || *dev >= 64) {
+        rt_set_err("device %d outside the 64 this library keeps tone scratch for", *dev);
+        return RT_E_INVALID;
+    }
+    return 0;
+}
+
 int tone_scratch(double **partial, double **sums)
 {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
-        return RT_E_INVALID;
+    const int rc = current_device(&dev);
+    if (rc)
+        return rc;
     std::lock_guard<std::mutex> lk(g_tone_mu);
     if (!g_tone[dev].partial) {
-        const hipError_t e = hipMalloc((void **)&g_tone[dev].partial, (2 * kToneBlocks + 4) * sizeof(double));
-        if (e != hipSuccess)
+        const hipError_t e = hipMalloc((void **)&g_tone[dev].partial, kScratchDoubles * sizeof(double));
+        if (e != hipSuccess) {
+            rt_set_err("allocating the tone step's partial sums failed: %s", hipGetErrorString(e));
             return -(int)e;
+        }
     }
     *partial = g_tone[dev].partial;
     *sums = g_tone[dev].partial + 2 * kToneBlocks;
@@ -172,6 +192,42 @@ uint32_t tone_grid(uint64_t n)
     return (uint32_t)(want < 1 ? 1 : want > kToneBlocks ? kToneBlocks : want);
 }
 
+int launched(const char *what)
+{
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+        return 0;
+    rt_set_err("%s: kernel launch failed: %s", what, hipGetErrorString(e));
+    return -(int)e;
+}
+
+/* both halves on `st`, partial sums and the three sums in the caller's scratch block */
+int tone_with(double *partial, double *sums, float *d_radiance, uint32_t *d_argb, uint64_t npixels, int op, float ldMax,
+              float lMax, int64_t key_pixel, hipStream_t st)
+{
+    if (op != RT_TONE_REINHARD)
+        key_pixel = -1; /* Ward's operator has no key pixel (raytrace.c:792-806) */
+    const uint32_t grid = tone_grid(npixels);
+    k_tone_sums<<<grid, RT_BLOCK, 0, st>>>(d_radiance, npixels, lMax, partial);
+    k_tone_finish<<<1, RT_BLOCK, 0, st>>>(partial, grid, d_radiance, lMax, key_pixel, sums);
+    k_tone_apply<<<grid * 4u, RT_BLOCK, 0, st>>>(d_radiance, d_argb, npixels, op, ldMax, lMax, sums, npixels,
+                                                  key_pixel >= 0);
+    return launched("rt_hip_tone");
+}
+
+int check_tone_args(const float *d_radiance, uint64_t npixels, int op, int64_t key_pixel)
+{
+    if (!d_radiance || (op != RT_TONE_WARD && op != RT_TONE_REINHARD)) {
+        rt_set_err("tone step: null frame or operator %d (RT_TONE_WARD, RT_TONE_REINHARD)", op);
+        return RT_E_INVALID;
+    }
+    if (key_pixel >= (int64_t)npixels) {
+        rt_set_err("tone step: key pixel %lld outside the %llu pixels", (long long)key_pixel, (unsigned long long)npixels);
+        return RT_E_INVALID;
+    }
+    return 0;
+}
+
 } // namespace
 
 extern "C" {
@@ -179,44 +235,59 @@ extern "C" {
 int rt_hip_tone_sums(const float *d_radiance, uint64_t npixels, float lMax, int64_t key_pixel, double *d_sums,
                      void *stream)
 {
-    if (!d_radiance || !d_sums || npixels == 0 || key_pixel >= (int64_t)npixels)
+    if (!d_sums) {
+        rt_set_err("rt_hip_tone_sums: null sums");
         return RT_E_INVALID;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (npixels == 0) { /* a rank that holds no pixel of the frame contributes zeros (and still joins the all-reduce) */
+        const hipError_t e = hipMemsetAsync(d_sums, 0, 3 * sizeof(double), st);
+        if (e != hipSuccess) {
+            rt_set_err("rt_hip_tone_sums: hipMemsetAsync failed: %s", hipGetErrorString(e));
+            return -(int)e;
+        }
+        return 0;
+    }
+    int rc = check_tone_args(d_radiance, npixels, RT_TONE_WARD, key_pixel);
+    if (rc)
+        return rc;
     double *partial, *own;
-    int rc = tone_scratch(&partial, &own);
+    rc = tone_scratch(&partial, &own);
     if (rc)
         return rc;
     const uint32_t grid = tone_grid(npixels);
-    hipStream_t st = (hipStream_t)stream;
     k_tone_sums<<<grid, RT_BLOCK, 0, st>>>(d_radiance, npixels, lMax, partial);
     k_tone_finish<<<1, RT_BLOCK, 0, st>>>(partial, grid, d_radiance, lMax, key_pixel, d_sums);
-    const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : -(int)e;
+    return launched("rt_hip_tone_sums");
 }
 
 int rt_hip_tone_apply(float *d_radiance, uint32_t *d_argb, uint64_t npixels, int op, float ldMax, float lMax,
                       const double *d_sums, uint64_t total_pixels, int use_key, void *stream)
 {
-    if (!d_radiance || !d_sums || npixels == 0 || total_pixels == 0 || (op != RT_TONE_WARD && op != RT_TONE_REINHARD))
+    if (npixels == 0)
+        return 0; /* nothing of the frame on this rank */
+    if (!d_radiance || !d_sums || total_pixels == 0 || (op != RT_TONE_WARD && op != RT_TONE_REINHARD)) {
+        rt_set_err("rt_hip_tone_apply: null argument, empty frame or operator %d", op);
         return RT_E_INVALID;
+    }
     k_tone_apply<<<tone_grid(npixels) * 4u, RT_BLOCK, 0, (hipStream_t)stream>>>(d_radiance, d_argb, npixels, op, ldMax,
                                                                                   lMax, d_sums, total_pixels, use_key);
-    const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : -(int)e;
+    return launched("rt_hip_tone_apply");
 }
 
 int rt_hip_tone(float *d_radiance, uint32_t *d_argb, uint64_t npixels, int op, float ldMax, float lMax,
                 int64_t key_pixel, void *stream)
 {
+    if (npixels == 0)
+        return 0;
+    int rc = check_tone_args(d_radiance, npixels, op, key_pixel);
+    if (rc)
+        return rc;
     double *partial, *sums;
-    int rc = tone_scratch(&partial, &sums);
+    rc = tone_scratch(&partial, &sums);
     if (rc)
         return rc;
-    if (op != RT_TONE_REINHARD)
-        key_pixel = -1; /* Ward's operator has no key pixel (raytrace.c:792-806) */
-    rc = rt_hip_tone_sums(d_radiance, npixels, lMax, key_pixel, sums, stream);
-    if (rc)
-        return rc;
-    return rt_hip_tone_apply(d_radiance, d_argb, npixels, op, ldMax, lMax, sums, npixels, key_pixel >= 0, stream);
+    return tone_with(partial, sums, d_radiance, d_argb, npixels, op, ldMax, lMax, key_pixel, (hipStream_t)stream);
 }
 
 } /* extern "C" */

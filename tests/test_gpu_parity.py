@@ -957,3 +957,39 @@ def test_tail_stream_with_small_queues_and_overflow_retries(torch_cuda, make_sce
         assert (st.shade_nodes, st.tree_nodes, st.queued_rays) == (st0.shade_nodes, st0.tree_nodes, st0.queued_rays)
         assert torch.equal(argb, want) and torch.equal(rad.view(torch.int32), want_rad.view(torch.int32))
     small.close()
+
+
+def test_scene_upload_finishes_the_render_in_flight(torch_cuda, make_scene):
+    """rt_hip_scene_upload while a render is pending: the render must be finished properly first -
+    overflow retries drained (small queues: the first plan overflows), the tail stream waited for - so
+    that its frame is complete and a following instrumented render does not run beside its tail."""
+    torch = torch_cuda
+    sc = make_scene("builtin")
+    W, H, s, d = 640, 480, 2, 8
+    cam = rt.prepare_camera(sc, W, H, s, d)
+    ref = rt.Context()
+    ref.upload(sc)
+    want, want_rad, st0 = render_dev(torch, ref, cam)
+    ref.close()
+    main, tail = torch.cuda.Stream(), torch.cuda.Stream()
+    ctx = rt.Context(queue_cap=1 << 18)
+    ctx.upload(sc)
+    ctx.set_tail_stream(tail.cuda_stream)
+    ctx.set_batch_samples(1 << 30)                 # plan one batch: it overflows and is re-rendered in halves
+    argb = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    rad = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    ctx.render_rows(cam, argb.data_ptr(), rad.data_ptr(), 0, H, main.cuda_stream)
+    ctx.upload(sc)                                 # same scene: the device copy is kept, the render finished
+    torch.cuda.synchronize()
+    assert np.array_equal(argb.cpu().numpy().view(np.uint32), want)
+    assert np.array_equal(rad.cpu().numpy().view(np.uint32), want_rad.view(np.uint32))
+    a2, r2, st2 = render_dev(torch, ctx, cam, stats=True)
+    assert np.array_equal(a2, want) and np.array_equal(r2.view(np.uint32), want_rad.view(np.uint32))
+    assert rays_of(st2) == rays_of(st0)
+    other = make_scene("syn64")                    # a different scene while a render is pending
+    ctx.render_rows(cam, argb.data_ptr(), rad.data_ptr(), 0, H, main.cuda_stream)
+    ctx.upload(other)
+    torch.cuda.synchronize()
+    assert np.array_equal(argb.cpu().numpy().view(np.uint32), want)
+    ctx.close()
