@@ -250,6 +250,18 @@ int  rt_hip_tone_sums(const float *d_radiance, uint64_t npixels, float lMax, int
 int  rt_hip_tone_apply(float *d_radiance, uint32_t *d_argb, uint64_t npixels, int op, float ldMax,
                        float lMax, const double *d_sums, uint64_t total_pixels, int use_key, void *stream);
 
+/* rt_hip_tone that allocates nothing.  No counterpart in the reference: it is for callers that cannot
+ * call hipMalloc - code under HIP graph capture, tight serving loops, harnesses that forbid allocation.
+ * Same arguments, same kernels and bit-identical results to rt_hip_tone; the partial sums live in a
+ * static device array of the library (16 KiB + 32 B per GPU, held until the process ends) instead of a
+ * block allocated on first use.  Limit: npixels <= RT_TONE_STATIC_MAX_PIXELS, larger frames are rejected
+ * with RT_E_INVALID.  Every call on a GPU uses that GPU's one array: calls that overlap on one GPU (two
+ * streams, two threads) race, like rt_hip_tone's.  The array's address is resolved once per device, by
+ * rt_hip_ctx_create or by the first call on that device (hipGetSymbolAddress; no allocation). */
+#define RT_TONE_STATIC_MAX_PIXELS (1ull << 28)
+int  rt_hip_tone_static(float *d_radiance, uint32_t *d_argb, uint64_t npixels, int op, float ldMax, float lMax,
+                        int64_t key_pixel, void *stream);
+
 /* Wait for the last rt_hip_render_rows, verify no queue overflowed (re-rendering finer
  * batches if one did) and return its counters.  stats may be NULL. */
 int  rt_hip_finish(rt_hip_ctx *ctx, rt_hip_stats *stats);

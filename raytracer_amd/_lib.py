@@ -17,6 +17,7 @@ EXPORTS = [
     "rt_poly_plane", "rt_scene_builtin", "rt_parse_scene", "rt_scene_free", "rt_scene_synthetic",
     "rt_write_image", "write_image", "rt_hip_selftest_arith", "rt_load_scene", "rt_hip_deinterleave",
     "rt_hip_render_devices", "rt_hip_tone", "rt_hip_tone_sums", "rt_hip_tone_apply", "rt_hip_selftest_grid",
+    "rt_hip_tone_static",
 ]
 
 _lib = None
@@ -59,6 +60,8 @@ def load():
     lib.rt_hip_selftest_grid.restype = i32
     lib.rt_hip_tone.argtypes = [vp, vp, u64, i32, f32, f32, C.c_int64, vp]
     lib.rt_hip_tone.restype = i32
+    lib.rt_hip_tone_static.argtypes = [vp, vp, u64, i32, f32, f32, C.c_int64, vp]
+    lib.rt_hip_tone_static.restype = i32
     lib.rt_hip_tone_sums.argtypes = [vp, u64, f32, C.c_int64, vp, vp]
     lib.rt_hip_tone_sums.restype = i32
     lib.rt_hip_tone_apply.argtypes = [vp, vp, u64, i32, f32, f32, vp, u64, i32, vp]

@@ -127,6 +127,12 @@ def tone(d_radiance, d_argb, npixels, op, ld_max, l_max, key_pixel=-1, stream=0)
           "rt_hip_tone")
 
 
+def tone_static(d_radiance, d_argb, npixels, op, ld_max, l_max, key_pixel=-1, stream=0):
+    """rt_hip_tone_static: rt_hip_tone without any allocation (static scratch block in the library)."""
+    check(load().rt_hip_tone_static(d_radiance, d_argb or None, npixels, op, ld_max, l_max, key_pixel, stream or None),
+          "rt_hip_tone_static")
+
+
 def tone_sums(d_radiance, npixels, l_max, key_pixel, d_sums, stream=0):
     check(load().rt_hip_tone_sums(d_radiance, npixels, l_max, key_pixel, d_sums, stream or None), "rt_hip_tone_sums")
 

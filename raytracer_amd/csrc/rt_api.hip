@@ -602,6 +602,8 @@ int rt_hip_ctx_create(rt_hip_ctx **out, int device, uint64_t max_queue_rays)
     cap = (cap + RT_SHARDS - 1) / RT_SHARDS * RT_SHARDS; /* whole shards */
     c->cap = cap;
     int rc = ctx_set_device(c);
+    if (!rc) /* the library's per-device set-up: the address of rt_hip_tone_static's scratch array */
+        rc = rt_tone_static_init();
     if (rc) {
         delete c;
         return rc;

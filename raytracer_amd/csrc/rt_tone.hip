@@ -29,6 +29,16 @@
 constexpr uint32_t kToneBlocks = 1024; /* partial sums per launch */
 constexpr size_t kScratchDoubles = 2 * kToneBlocks + 4; /* 2 * kToneBlocks partials, then 3 sums (+1 pad) */
 
+/*
+ * rt_hip_tone_static: the tone step's scratch block (partial sums + the three sums) as a file-scope
+ * device array - 16 KiB + 32 B on every GPU the library runs on, held until the process ends - for
+ * callers that cannot allocate.  In host code `scratch` is only a handle for hipGetSymbolAddress, never
+ * a device address: the address is resolved once per device, with that device current
+ * (rt_tone_static_init), and kept in g_static_ptr[device]; kernels, and anything else that needs the
+ * memory, get that pointer.
+ */
+static __device__ __align__(256) double scratch[kScratchDoubles];
+
 namespace {
 
 __device__ __forceinline__ float luminance(float r, float g, float b)
@@ -152,6 +162,7 @@ struct ToneScratch {
 std::mutex g_tone_mu;
 ToneScratch g_tone[64];
 
+double *g_static_ptr[64] = {nullptr}; /* device address of `scratch` per device (rt_tone_static_init) */
 
 int current_device(int *dev)
 {
@@ -230,6 +241,25 @@ int check_tone_args(const float *d_radiance, uint64_t npixels, int op, int64_t k
 
 } // namespace
 
+int rt_tone_static_init(void)
+{
+    int dev = 0;
+    const int rc = current_device(&dev);
+    if (rc)
+        return rc;
+    std::lock_guard<std::mutex> lk(g_tone_mu);
+    if (!g_static_ptr[dev]) {
+        double *ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) {
+            rt_set_err("hipGetSymbolAddress(tone scratch) on device %d failed: %s", dev, hipGetErrorString(e));
+            return e != hipSuccess ? -(int)e : RT_E_INVALID;
+        }
+        g_static_ptr[dev] = ptr;
+    }
+    return 0;
+}
+
 extern "C" {
 
 int rt_hip_tone_sums(const float *d_radiance, uint64_t npixels, float lMax, int64_t key_pixel, double *d_sums,
@@ -288,6 +318,31 @@ int rt_hip_tone(float *d_radiance, uint32_t *d_argb, uint64_t npixels, int op, f
     if (rc)
         return rc;
     return tone_with(partial, sums, d_radiance, d_argb, npixels, op, ldMax, lMax, key_pixel, (hipStream_t)stream);
+}
+
+int rt_hip_tone_static(float *d_radiance, uint32_t *d_argb, uint64_t npixels, int op, float ldMax, float lMax,
+                       int64_t key_pixel, void *stream)
+{
+    if (npixels > RT_TONE_STATIC_MAX_PIXELS) {
+        rt_set_err("rt_hip_tone_static: %llu pixels exceed the %llu this entry point takes (RT_TONE_STATIC_MAX_PIXELS)",
+                   (unsigned long long)npixels, (unsigned long long)RT_TONE_STATIC_MAX_PIXELS);
+        return RT_E_INVALID;
+    }
+    if (npixels == 0)
+        return 0;
+    int rc = check_tone_args(d_radiance, npixels, op, key_pixel);
+    if (rc)
+        return rc;
+    int dev = 0;
+    if ((rc = current_device(&dev)))
+        return rc;
+    if (!g_static_ptr[dev] && (rc = rt_tone_static_init())) /* first call on this device (no context made yet) */
+        return rc;
+    double *const block = g_static_ptr[dev];
+    /* the kernels write every partial and every sum they later read: nothing of the last call's
+     * contents needs clearing */
+    return tone_with(block, block + 2 * kToneBlocks, d_radiance, d_argb, npixels, op, ldMax, lMax, key_pixel,
+                     (hipStream_t)stream);
 }
 
 } /* extern "C" */
