@@ -153,6 +153,10 @@ def main():
                     help="N > 1: run the all-gather + de-interleave on a second stream behind events, so that they "
                          "overlap the next frame's render (default), or on the render stream (the frames then wait "
                          "for their gathers: step = render + collective)")
+    ap.add_argument("--numerics", choices=["fast", "exact"], default="fast",
+                    help="fast (default): the tolerance build of the trace kernels (FMA, 1-ulp rcp / rsq / sqrt; pixels "
+                         "within the north star's +-1 LSB / 1e-4); exact: every operation rounded like the reference's "
+                         "x86 build (pixels bit-identical to the reference's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -192,6 +196,7 @@ def main():
     for _ in range(inflight):
         c = rt.Context(device=local_rank)
         c.upload(scene)
+        c.set_numerics(rt.NUMERICS_FAST if args.numerics == "fast" else rt.NUMERICS_EXACT)
         if tail is not None:
             c.set_tail_stream(tail.cuda_stream)
         ctxs.append(c)
@@ -310,6 +315,7 @@ def main():
                        # the sub-total without shadow rays, and its rate
                        "rays_per_step_without_shadow": (rays_all - shadow_all) / args.steps,
                        "mrays_per_s_without_shadow": (rays_all - shadow_all) / dt_max / 1e6,
+                       "numerics": args.numerics,
                        "frames_in_flight": inflight, "streams": "one per frame" if args.overlap else ("shared + tail stream" if tail is not None else "shared"),
                        "parallelism": "1 GPU" if world == 1 else f"cyclic 8-row blocks over {world} GPUs"},
             "roofline": {"bound": "fp32_valu", "kernel": "k_primary", "achieved": achieved,

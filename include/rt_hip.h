@@ -283,6 +283,20 @@ int  rt_hip_render_stats(rt_hip_ctx *ctx, const rt_camera *camera,
 #define RT_SHADE_PHONGBLINN  1
 int  rt_hip_ctx_set_shading(rt_hip_ctx *ctx, int model);
 
+/* Numerics of the context's renders.  RT_NUMERICS_EXACT (the default): every float operation rounded like
+ * the reference's x86-64 build, in its order - divides and square roots correctly rounded, the reference's
+ * double-precision islands in double, no fused multiply-adds - so that pixels equal the reference's bit
+ * for bit (but for glibc's powf rounding).  RT_NUMERICS_FAST: the tolerance the north star grants (8-bit
+ * pixels within 1 LSB and radiance within 1e-4 relative on >= 99.9 % of the pixels): fused multiply-adds,
+ * the hardware's 1-ulp reciprocal / reciprocal square root / square root, float sphere roots and
+ * refraction term, v_exp/v_log for the highlight power.  Same pipeline, ~2x fewer vector instructions.
+ * Instrumented renders (rt_hip_render_stats) and RT_SHADE_PHONGBLINN always run the exact kernels.
+ * rt_hip_render / raytrace() follow RT_HIP_NUMERICS=exact|fast in the environment.  No counterpart in
+ * the reference (one build, one set of compiler flags: Makefile:5-20).  Returns 0 or RT_E_INVALID. */
+#define RT_NUMERICS_EXACT 0
+#define RT_NUMERICS_FAST  1
+int  rt_hip_ctx_set_numerics(rt_hip_ctx *ctx, int mode);
+
 /* Optional second stream (a hipStream_t; NULL = none, the default) for the tail of every batch this
  * context renders.  A batch of the reference's scene spends 0.29 ms in kernels that fill the GPU
  * (k_primary, the first two bounce levels) and 0.14 ms in the sparse deep levels, the folds and the

@@ -119,6 +119,7 @@ def render(scene, cam, row0=0, nrows=None, want_radiance=True, devices=None):
 
 TONE_WARD, TONE_REINHARD = 1, 2
 SHADE_PHONG, SHADE_PHONGBLINN = 0, 1
+NUMERICS_EXACT, NUMERICS_FAST = 0, 1
 
 
 def tone(d_radiance, d_argb, npixels, op, ld_max, l_max, key_pixel=-1, stream=0):
@@ -166,6 +167,11 @@ class Context:
         """SHADE_PHONG (get_shade_color_phong, what the reference calls) or SHADE_PHONGBLINN (its unused
         get_shade_color_phongblinn, raytrace.c:574-685)"""
         check(load().rt_hip_ctx_set_shading(self._h, int(model)), "rt_hip_ctx_set_shading")
+
+    def set_numerics(self, mode):
+        """NUMERICS_EXACT (the reference's rounding, bit for bit) or NUMERICS_FAST (the north star's tolerance:
+        fused multiply-adds, 1-ulp rcp / rsq / sqrt) - rt_hip_ctx_set_numerics"""
+        check(load().rt_hip_ctx_set_numerics(self._h, int(mode)), "rt_hip_ctx_set_numerics")
 
     def set_tail_stream(self, stream):
         """hipStream_t (int) for the latency-bound tail of every batch, 0 = none (rt_hip_ctx_set_tail_stream)"""

@@ -93,6 +93,7 @@ struct rt_hip_ctx {
     /* options */
     bool timing = false;
     int shading = RT_SHADE_PHONG;
+    int numerics = RT_NUMERICS_EXACT;
     /* optional second stream for the latency-bound tail of a batch (rt_hip_ctx_set_tail_stream) */
     hipStream_t tail_stream = nullptr;
     hipEvent_t head_done = nullptr, tail_done = nullptr;
@@ -240,7 +241,12 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
         c->ev.push_back(e1);
         HIP_TRY(hipEventRecord(e0, st));
     }
-    rt_launch_primary(c->S, c->C, Wk, R, stats, c->shading == RT_SHADE_PHONGBLINN, st);
+    /* the tolerance build has the plain Phong kernels only: instrumented and phong-blinn renders run the exact ones */
+    const bool fast = c->numerics == RT_NUMERICS_FAST && !stats && c->shading == RT_SHADE_PHONG;
+    if (fast)
+        rt_launch_primary_fast(c->S, c->C, Wk, R, st);
+    else
+        rt_launch_primary(c->S, c->C, Wk, R, stats, c->shading == RT_SHADE_PHONGBLINN, st);
     if (timed)
         HIP_TRY(hipEventRecord(c->ev.back(), st));
     auto to_tail = [&]() -> int {
@@ -255,7 +261,11 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
             if (rc)
                 return rc;
         }
-        rt_launch_bounce(c->S, c->C, Wk, d, stats, c->seen_valid ? (c->seen_hits[d] ? c->seen_hits[d] : 1u) : 0u, st);
+        const uint32_t expect = c->seen_valid ? (c->seen_hits[d] ? c->seen_hits[d] : 1u) : 0u;
+        if (fast)
+            rt_launch_bounce_fast(c->S, c->C, Wk, d, expect, st);
+        else
+            rt_launch_bounce(c->S, c->C, Wk, d, stats, expect, st);
     }
     if (cut == depth + 1u) {
         const int rc = to_tail();
@@ -689,6 +699,18 @@ int rt_hip_ctx_set_shading(rt_hip_ctx *c, int model)
         return RT_E_INVALID;
     }
     c->shading = model;
+    return 0;
+}
+
+int rt_hip_ctx_set_numerics(rt_hip_ctx *c, int mode)
+{
+    if (!c || (mode != RT_NUMERICS_EXACT && mode != RT_NUMERICS_FAST)) {
+        set_err("numerics mode %d is neither RT_NUMERICS_EXACT nor RT_NUMERICS_FAST", mode);
+        return RT_E_INVALID;
+    }
+    if (mode != c->numerics)
+        c->seen_valid = false; /* (a handful of samples may take the other side of a threshold: level sizes can move) */
+    c->numerics = mode;
     return 0;
 }
 
@@ -1282,6 +1304,17 @@ static int shading_from_env(void)
     return -1; /* rejected by rt_hip_ctx_set_shading */
 }
 
+/* RT_HIP_NUMERICS=fast: the host-pointer entry points render with the tolerance build of the kernels */
+static int numerics_from_env(void)
+{
+    const char *e = getenv("RT_HIP_NUMERICS");
+    if (!e || !*e || !strcmp(e, "exact"))
+        return RT_NUMERICS_EXACT;
+    if (!strcmp(e, "fast"))
+        return RT_NUMERICS_FAST;
+    return -1; /* rejected by rt_hip_ctx_set_numerics */
+}
+
 int rt_hip_render(const rt_scene *scene, const rt_camera *cam, rt_framebuffer *fb)
 {
     if (!scene || !cam || !fb || !fb->argb) {
@@ -1324,6 +1357,8 @@ int rt_hip_render(const rt_scene *scene, const rt_camera *cam, rt_framebuffer *f
             return rc;
     }
     rc = rt_hip_ctx_set_shading(g_ctx, shading_from_env());
+    if (!rc)
+        rc = rt_hip_ctx_set_numerics(g_ctx, numerics_from_env());
     if (rc)
         return rc;
     rc = rt_hip_scene_upload(g_ctx, scene);
@@ -1461,7 +1496,8 @@ int rt_hip_render_devices(const rt_scene *scene, const rt_camera *cam, rt_frameb
             break;
         if (!s.stream)
             HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-        if ((rc = rt_hip_ctx_set_shading(s.ctx, shading_from_env())) || (rc = rt_hip_scene_upload(s.ctx, scene)))
+        if ((rc = rt_hip_ctx_set_shading(s.ctx, shading_from_env())) ||
+            (rc = rt_hip_ctx_set_numerics(s.ctx, numerics_from_env())) || (rc = rt_hip_scene_upload(s.ctx, scene)))
             break;
         if (local_px > s.argb_px) {
             if (s.d_argb) (void)hipFree(s.d_argb);

@@ -186,6 +186,11 @@ static_assert(2 * ST_COUNT <= CNT_STATS_STRIDE, "statistics do not fit their lin
 void rt_launch_fold_deep(const DevWork &Wk, uint32_t top_level, uint32_t bottom_level, hipStream_t stream);
 void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
                        bool stats, bool blinn, hipStream_t stream);
+/* the same two from the tolerance build of the kernels (rt_kernels.hip compiled with -DRT_FAST) */
+void rt_launch_primary_fast(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
+                            hipStream_t stream);
+void rt_launch_bounce_fast(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t level,
+                           uint32_t expect, hipStream_t stream);
 /* `expect` = entries per shard the launch is expected to find (0 = unknown: a full resident set).
  * It only sizes the grid; the kernels stride over whatever the counters say. */
 void rt_launch_bounce(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t level,

@@ -45,7 +45,19 @@
 #define RT_WPE 1 /* min waves per SIMD asked of the register allocator (launch_bounds 2nd arg) */
 #endif
 
-namespace {
+/* This file is compiled twice (csrc/Makefile): as it stands - every operation rounded like the reference's
+ * x86 build - and with -DRT_FAST -ffp-contract=fast, the tolerance build (rt_arith.h).  The two sets
+ * of kernels live in namespaces of their own so that profiles tell them apart (rt_exact::k_primary,
+ * rt_fast::k_primary); the fast set has no instrumented and no phong-blinn variants. */
+#ifdef RT_FAST
+#define RT_NSNAME rt_fast
+constexpr bool kFast = true;
+#else
+#define RT_NSNAME rt_exact
+constexpr bool kFast = false;
+#endif
+
+namespace RT_NSNAME {
 
 struct Ray {
     float ox, oy, oz;
@@ -141,21 +153,43 @@ __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, fl
  * reciprocal); the three quotients share one refined reciprocal (rt_arith.h) */
 __device__ __forceinline__ void normalize3(float &x, float &y, float &z)
 {
+#ifdef RT_FAST
+    const float rm = rsq_approx((x * x + y * y) + z * z);
+    x = x * rm; y = y * rm; z = z * rm;
+#else
     const float m = mag3(x, y, z);
     const float rm = rcp_refined(m);
     x = div_with(x, m, rm);
     y = div_with(y, m, rm);
     z = div_with(z, m, rm);
+#endif
+}
+
+/* ray_create's length and its reciprocal (ray.c:34-37): mag = |d|, inv = 1.0f / mag */
+__device__ __forceinline__ void length_and_reciprocal(float dx, float dy, float dz, float &mag, float &inv)
+{
+#ifdef RT_FAST
+    const float l2 = (dx * dx + dy * dy) + dz * dz;
+    inv = rsq_approx(l2);
+    mag = l2 * inv;
+#else
+    mag = mag3(dx, dy, dz);
+    inv = div_with(1.0f, mag, rcp_refined(mag));
+#endif
 }
 
 /* 1.0f / m as ray_create computes it (ray.c:36-37) */
 __device__ __forceinline__ float recip_rn(float m) { return div_with(1.0f, m, rcp_refined(m)); }
 
 /* ray_tinypush ray.c:72-86: origin += normalize(direction) * 0.001f (normalize divides) */
+/* UNIT: the caller knows the direction to be of unit length (to rounding); the tolerance build then
+ * skips the normalisation, the exact build never does (the reference divides whatever it gets) */
+template <bool UNIT = false>
 __device__ __forceinline__ void tinypush(Ray &r)
 {
     float nx = r.dx, ny = r.dy, nz = r.dz;
-    normalize3(nx, ny, nz);
+    if constexpr (!(kFast && UNIT))
+        normalize3(nx, ny, nz);
     r.ox = r.ox + nx * 0.001f;
     r.oy = r.oy + ny * 0.001f;
     r.oz = r.oz + nz * 0.001f;
@@ -168,12 +202,18 @@ __device__ __forceinline__ void tinypush(Ray &r)
  * B >= 0 gives wOne <= 0 without needing the square root (w = 0, or -B/2 when det == 0). */
 __device__ __forceinline__ float sphere_distance(float B, float det)
 {
+#ifdef RT_FAST
+    /* the same selection in float: wOne = (-B - sqrt(det)) / 2, clamped at 0 unless det == 0 */
+    const float wOne = (-B - sqrt_rn(det)) * 0.5f;
+    return (det == 0.0f || wOne > 0.0f) ? wOne : 0.0f;
+#else
     if (det == 0.0f)
         return (float)((double)(-B) * 0.5);
     if (!(B < 0.0f))
         return 0.0f;
     const float wOne = (float)(((double)(-B) - sqrt_rn_f64_pos((double)det)) * 0.5); /* det > 0 here */
     return wOne > 0.0f ? wOne : 0.0f;
+#endif
 }
 
 /*
@@ -274,8 +314,8 @@ __device__ __forceinline__ bool polygon_inside_exact(const float4 *vtx, uint32_t
     const float twopi = 6.2831853071795864769f;
     const float sf = polygon_angle_sum<float>(vtx, nv, px, py, pz);
     const float margin = (sf + 0.001f) - twopi;
-    if (fabsf(margin) > fmaxf(1e-4f, 4e-6f * (float)nv)) /* NaN (a cosine outside [-1,1]) falls through */
-        return margin > 0.0f;
+    if (kFast || fabsf(margin) > fmaxf(1e-4f, 4e-6f * (float)nv)) /* NaN (a cosine outside [-1,1]) falls through */
+        return margin > 0.0f; /* (the tolerance build takes the float sum's word for it) */
     /* The same float cosines again, folded into the rotation.  Both edge vectors are rebuilt per
      * edge (same expressions, same values) so that nothing but the rotation lives across the
      * double-precision square root: this path runs for a few samples per frame, but its register
@@ -325,7 +365,7 @@ __device__ __forceinline__ bool quad_inside_exact(const Quad &q)
     const float twopi = 6.2831853071795864769f;
     const float sf = ((acos_screen(c[0]) + acos_screen(c[1])) + acos_screen(c[2])) + acos_screen(c[3]);
     const float margin = (sf + 0.001f) - twopi;
-    if (fabsf(margin) > 1e-4f)
+    if (kFast || fabsf(margin) > 1e-4f)
         return margin > 0.0f;
     Rot z = rot_start();
 #pragma unroll 1
@@ -410,6 +450,11 @@ __device__ __forceinline__ bool polygon_inside(const float4 *vtx, const float4 *
  * device powf (<= 1 ulp). */
 __device__ __forceinline__ float phong_pow(float s, float ke)
 {
+#ifdef RT_FAST
+    /* s >= 0: s^ke = 2^(ke * log2 s), v_log_f32 and v_exp_f32 (1 ulp each; the product's error is
+     * ~ke * |log2 s| * 1e-7 relative).  log2(0) = -inf gives 0 for ke > 0; ke == 0 gives 1 like powf. */
+    return ke == 0.0f ? 1.0f : __builtin_amdgcn_exp2f(ke * __builtin_amdgcn_logf(s));
+#else
     const int e = (int)ke;
     if ((float)e == ke && e >= 0 && e <= 4096) {
         double r = 1.0, b = (double)s;
@@ -421,6 +466,7 @@ __device__ __forceinline__ float phong_pow(float s, float ke)
         return (float)r;
     }
     return powf(s, ke);
+#endif
 }
 
 /* Cooperative copy of n float4 from HBM to LDS by the whole block. */
@@ -1019,11 +1065,11 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
         Ray sh;
         sh.ox = px; sh.oy = py; sh.oz = pz;
         sh.dx = lp.x - px; sh.dy = lp.y - py; sh.dz = lp.z - pz;
-        sh.mag = mag3(sh.dx, sh.dy, sh.dz);
-        const float inv = recip_rn(sh.mag);
+        float inv;
+        length_and_reciprocal(sh.dx, sh.dy, sh.dz, sh.mag, inv);
         sh.dx = sh.dx * inv; sh.dy = sh.dy * inv; sh.dz = sh.dz * inv;
         if constexpr (!BLINN) /* raytrace.c:613-616: the older routine does not push its shadow rays */
-            tinypush(sh);
+            tinypush<true>(sh);
         float sd;
         uint32_t sobj;
         intersect_all<GRID, true, true, STATS, !TABLDS>(S, lds_poly, lds_sph, hit, sh, exc_sph, exc_poly, sd,
@@ -1078,7 +1124,8 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
                     sx = back[7 * RT_BLOCK]; sy = back[8 * RT_BLOCK]; sz = back[9 * RT_BLOCK];
                 } else {
                     sx = lp.x - px; sy = lp.y - py; sz = lp.z - pz;
-                    const float inv = recip_rn(mag3(sx, sy, sz));
+                    float len, inv;
+                    length_and_reciprocal(sx, sy, sz, len, inv);
                     sx = sx * inv; sy = sy * inv; sz = sz * inv;
                 }
                 const float t = dot3(sx, sy, sz, Nx, Ny, Nz);
@@ -1189,14 +1236,19 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
         Ray tr;
         tr.ox = tr.oy = tr.oz = tr.dx = tr.dy = tr.dz = tr.mag = 0.0f;
         if (want_t) { /* transmission ray raytrace.c:455-537 */
-            float nit = 1.0f / mD.x;
+#ifdef RT_FAST
+            const float inv_n = rcp_refined(mD.x);
+#else
+            const float inv_n = 1.0f / mD.x;
+#endif
+            float nit = inv_n;
             float edx, edy, edz;
             eye_src.direction(edx, edy, edz);
             const float Tx = edx * nit, Ty = edy * nit, Tz = edz * nit;
             const float cs = dot3(Vx, Vy, Vz, Nx, Ny, Nz);
             float Fx = Nx, Fy = Ny, Fz = Nz;
             if (cs < 0.0f) { /* inside the object moving out */
-                nit = 1.0f / nit;
+                nit = kFast ? mD.x : 1.0f / nit;
                 Fx = Nx * -1.0f; Fy = Ny * -1.0f; Fz = Nz * -1.0f;
             }
             const float det = 1.0f + (nit * nit) * (cs * cs - 1.0f);
@@ -1206,7 +1258,11 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
                 tr.dx = Fx * t2x - Vx; tr.dy = Fy * t2x - Vy; tr.dz = Fz * t2x - Vz;
                 tr.mag = 999999.0f;
             } else { /* :517-525: 1/n (not nit) times cos, minus a double sqrt */
-                const float k = (float)((double)((1.0f / mD.x) * cs) - sqrt((double)det));
+#ifdef RT_FAST
+                const float k = inv_n * cs - sqrt_rn(det);
+#else
+                const float k = (float)((double)(inv_n * cs) - sqrt((double)det));
+#endif
                 tr.dx = Tx + Fx * k; tr.dy = Ty + Fy * k; tr.dz = Tz + Fz * k;
                 tr.mag = 99999.9f;
             }
@@ -1217,7 +1273,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
             cr.ox = px; cr.oy = py; cr.oz = pz;
             cr.dx = Nx * t2x - Vx; cr.dy = Ny * t2x - Vy; cr.dz = Nz * t2x - Vz;
             cr.mag = 9999999.9f;
-            tinypush(cr);
+            tinypush<true>(cr); /* |2 (V.N) N - V| = 1 for unit V, N */
         }
         park[0 * RT_BLOCK] = tr.ox; park[1 * RT_BLOCK] = tr.oy; park[2 * RT_BLOCK] = tr.oz;
         park[3 * RT_BLOCK] = tr.dx; park[4 * RT_BLOCK] = tr.dy; park[5 * RT_BLOCK] = tr.dz;
@@ -1351,10 +1407,14 @@ __device__ __forceinline__ void primary_ray(const float *cam, float fu0, float f
     const float sy = (cam[CAM_SHIFTN + 1] + cam[CAM_U + 1] * fu) + cam[CAM_V + 1] * fv;
     const float sz = (cam[CAM_SHIFTN + 2] + cam[CAM_U + 2] * fu) + cam[CAM_V + 2] * fv;
     r.ox = cam[CAM_EYE + 0]; r.oy = cam[CAM_EYE + 1]; r.oz = cam[CAM_EYE + 2];
-    const float tx = r.ox + sx, ty = r.oy + sy, tz = r.oz + sz;
-    r.dx = tx - r.ox; r.dy = ty - r.oy; r.dz = tz - r.oz;
-    r.mag = mag3(r.dx, r.dy, r.dz);
-    const float inv = recip_rn(r.mag);
+    if constexpr (kFast) { /* (eye + shift) - eye = shift up to rounding */
+        r.dx = sx; r.dy = sy; r.dz = sz;
+    } else {
+        const float tx = r.ox + sx, ty = r.oy + sy, tz = r.oz + sz;
+        r.dx = tx - r.ox; r.dy = ty - r.oy; r.dz = tz - r.oz;
+    }
+    float inv;
+    length_and_reciprocal(r.dx, r.dy, r.dz, r.mag, inv);
     r.dx = r.dx * inv; r.dy = r.dy * inv; r.dz = r.dz * inv;
 }
 
@@ -1765,6 +1825,7 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_BOUNCE1 : RT_WPE)) v
     flush_tally<STATS>(st, tl, false);
 }
 
+#ifndef RT_FAST /* the kernels below do no arithmetic a tolerance could speed up: one copy, shared by both builds */
 /* colour of a tree node once both children are known: raytrace.c:440-442, 547-549, 562 */
 __device__ __forceinline__ uint32_t fold_values(const float4 A, const float2 K, const float4 cr,
                                                 const float4 ct, float out[3])
@@ -1997,12 +2058,16 @@ __global__ __launch_bounds__(RT_BLOCK) void k_selftest_grid(DevScene S, const fl
     out[4 * i + 3] = __float_as_uint(found ? d : 0.0f);
 }
 
-} // namespace
+#endif /* !RT_FAST */
+
+} // namespace RT_NSNAME
+using namespace RT_NSNAME;
 
 /* ------------------------------------------------------------------------------------------ */
 /* launch wrappers                                                                            */
 /* ------------------------------------------------------------------------------------------ */
 
+#ifndef RT_FAST
 int rt_scene_shape(const DevScene &S)
 {
     static const bool off = getenv("RT_HIP_NO_SHAPES") != nullptr; /* development: generic kernels only */
@@ -2024,6 +2089,24 @@ size_t rt_scene_lds_bytes(const DevScene &S)
            (S.tabInLds ? (size_t)(S.tabSlots + S.nSph + S.nPoly) * sizeof(float4) : 0); /* + eye terms */
 }
 
+#endif /* !RT_FAST */
+
+#ifdef RT_FAST
+/* the tolerance build's kernels: plain Phong renders only (the instrumented and phong-blinn variants
+ * exist in the exact build alone; rt_api.hip routes those there) */
+void rt_launch_primary_fast(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
+                            hipStream_t stream)
+{
+    const dim3 grid((C.W + 31u) / 32u, R.ntiles);
+    const size_t lds = rt_scene_lds_bytes(S);
+    const bool grid_scene = S.nSph > RT_TILE_SPHERES;
+    void (*kernel)(DevScene, DevCamera, DevWork, DevRows) =
+        grid_scene ? k_primary<true, false, false, 0>
+        : rt_scene_shape(S) == 1 ? k_primary<false, false, true, 1>
+        : S.tabInLds ? k_primary<false, false, true, 0> : k_primary<false, false, false, 0>;
+    kernel<<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, R);
+}
+#else
 void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
                        bool stats, bool blinn, hipStream_t stream)
 {
@@ -2050,6 +2133,7 @@ void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk,
     static const size_t pad_to = [] { const char *e = getenv("RT_HIP_PRIMARY_LDS"); return e ? (size_t)atol(e) : 0; }();
     kernel<<<grid, RT_BLOCK, lds < pad_to && pad_to <= 65536 ? pad_to : lds, stream>>>(S, C, Wk, R);
 }
+#endif
 
 /*
  * Grid of a queue-draining kernel: RT_SHARDS shards x slices, grid-strided over each shard's
@@ -2095,6 +2179,20 @@ static uint32_t queue_grid(const DevWork &Wk, const void *kernel, size_t lds, ui
     return slices * RT_SHARDS;
 }
 
+#ifdef RT_FAST
+void rt_launch_bounce_fast(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t level,
+                           uint32_t expect, hipStream_t stream)
+{
+    const size_t lds = rt_scene_lds_bytes(S);
+    const bool grid_scene = S.nSph > RT_TILE_SPHERES;
+    void (*kernel)(DevScene, DevCamera, DevWork, uint32_t) =
+        grid_scene ? k_bounce<true, false, false, 0>
+        : rt_scene_shape(S) == 1 ? k_bounce<false, false, true, 1>
+        : S.tabInLds ? k_bounce<false, false, true, 0> : k_bounce<false, false, false, 0>;
+    const uint32_t grid = queue_grid(Wk, (const void *)kernel, lds, expect);
+    kernel<<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, level);
+}
+#else
 void rt_launch_bounce(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t level,
                       bool stats, uint32_t expect, hipStream_t stream)
 {
@@ -2175,3 +2273,4 @@ void rt_launch_publish(uint32_t *counters, uint32_t *mirror, uint32_t words, hip
     const uint32_t n16 = words / 4u; /* the block is a whole number of 16-byte pieces (rt_device.h) */
     k_publish<<<(n16 + RT_BLOCK - 1) / RT_BLOCK, RT_BLOCK, 0, stream>>>((uint4 *)counters, (uint4 *)mirror, n16);
 }
+#endif /* RT_FAST */

@@ -24,7 +24,7 @@ def run_bench(args, env_extra=None):
 
 @pytest.mark.parametrize("tail", ["on", "off"])
 def test_single_gpu_line_has_the_contract_fields(tail):
-    d = run_bench(["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--tail-stream", tail])
+    d = run_bench(["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--tail-stream", tail, "--numerics", "exact"])
     assert d["config"]["streams"] == ("shared + tail stream" if tail == "on" else "shared")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline"):
