@@ -992,8 +992,15 @@ int rt_hip_scene_upload(rt_hip_ctx *c, const rt_scene *sc)
             info.y = __builtin_bit_cast(float, (uint32_t)pg.nVerticies);
             info.z = __builtin_bit_cast(float, i);
             info.w = 0.f;
-            infos.push_back(info);
             edge_screen_data(pg, edges);
+            {   /* largest gradient of the polygon's scaled edge equations: how fast the screening value can
+                 * move with the hit point (classify_pixel in rt_kernels.hip); rounded up */
+                float gmax = 0.f;
+                for (size_t e = edges.size() - pg.nVerticies; e < edges.size(); ++e)
+                    gmax = fmaxf(gmax, sqrtf(edges[e].x * edges[e].x + edges[e].y * edges[e].y + edges[e].z * edges[e].z));
+                info.w = gmax * 1.0001f;
+            }
+            infos.push_back(info);
             for (uint32_t v = 0; v < pg.nVerticies; ++v)
                 verts.push_back(make_float4(pg.vertex[v].x, pg.vertex[v].y, pg.vertex[v].z, pg.vertex[v].w));
             g = make_float4(pg.plane.A, pg.plane.B, pg.plane.C, 0.f);

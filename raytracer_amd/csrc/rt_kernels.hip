@@ -661,8 +661,9 @@ __device__ __forceinline__ void intersect_all(const DevScene &S, const float4 *l
                                               float4 *lds_sph, bool active, const Ray &r,
                                               uint32_t exc_sph, uint32_t exc_poly, float &out_d,
                                               uint32_t &out_obj, Tally<STATS> &tl,
-                                              const float4 *eye_terms = nullptr)
+                                              const float4 *eye_terms = nullptr, bool no_spheres = false)
 {
+    /* no_spheres (wave-uniform): the caller has shown that no lane's ray can meet a sphere (classify_pixel) */
     /* EYE: the ray starts at the eye, like every primary ray, so the terms of the tests that depend on
      * the origin alone were evaluated once per block by stage_eye_terms (same expressions, same
      * rounding): (o - c, 4*(|o - c|^2 - r^2)) per sphere, -(n.o + F) per polygon. */
@@ -706,7 +707,7 @@ __device__ __forceinline__ void intersect_all(const DevScene &S, const float4 *l
             }
         }
     };
-    if (GRID) {
+    if (GRID && !no_spheres) {
         /* the grid is only exact for rays the reference's test treats (almost) geometrically: a
          * direction of unit length (shorter ones are fine too: the test then accepts LESS than
          * geometry, but the reported distance is off the sphere, so they walk without early exit) and
@@ -725,7 +726,7 @@ __device__ __forceinline__ void intersect_all(const DevScene &S, const float4 *l
                 grid_walk<FILTERED, ANYHIT, STATS, false>(S, r, found, d, discriminant, candidate, tl, exc_sph);
         }
         wave_loop_all<FILTERED, STATS>(S, active && !walk, r, exc_sph, found, d, best_k, tl);
-    } else if (active) {
+    } else if (!GRID && active && !no_spheres) {
         const uint32_t cnt = S.nSph;
         uint32_t j = 0;
         if (BIG) {
@@ -1091,23 +1092,39 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     float eox, eoy, eoz;
     eye_src.origin(eox, eoy, eoz);
 
-    /* pass B (raytrace.c:349-384) */
-    if (hit && n_lights != 0) {
+    /* the tolerance build has registers to spare (63 of the 72 that seven waves per SIMD allow): normal and
+     * view vector are built once and stay; the exact build builds them again for the spawn (below) */
+    float Nx = 0.f, Ny = 0.f, Nz = 0.f, Vx = 0.f, Vy = 0.f, Vz = 0.f;
+    if (kFast && hit) {
         const float4 gD = tab[rec + RT_OBJ_GEOM];
         const float4 gE = tab[rec + RT_OBJ_SHAPE];
-        const float ke = tab[rec + RT_OBJ_PHONG].y;
-        /* normal: geometry.c:37-57 */
-        float Nx, Ny, Nz;
         if (__float_as_uint(gD.y) == 1u) {
-            const float nx = px - gE.x, ny = py - gE.y, nz = pz - gE.z;
-            Nx = nx; Ny = ny; Nz = nz;
+            Nx = px - gE.x; Ny = py - gE.y; Nz = pz - gE.z;
             normalize3(Nx, Ny, Nz);
         } else {
             Nx = gE.x; Ny = gE.y; Nz = gE.z;
         }
-        /* V = normalize(eye.origin - pt) raytrace.c:318-320 */
-        float Vx = eox - px, Vy = eoy - py, Vz = eoz - pz;
+        Vx = eox - px; Vy = eoy - py; Vz = eoz - pz;
         normalize3(Vx, Vy, Vz);
+    }
+    /* pass B (raytrace.c:349-384) */
+    if (hit && n_lights != 0) {
+        const float ke = tab[rec + RT_OBJ_PHONG].y;
+        if constexpr (!kFast) {
+            const float4 gD = tab[rec + RT_OBJ_GEOM];
+            const float4 gE = tab[rec + RT_OBJ_SHAPE];
+            /* normal: geometry.c:37-57 */
+            if (__float_as_uint(gD.y) == 1u) {
+                const float nx = px - gE.x, ny = py - gE.y, nz = pz - gE.z;
+                Nx = nx; Ny = ny; Nz = nz;
+                normalize3(Nx, Ny, Nz);
+            } else {
+                Nx = gE.x; Ny = gE.y; Nz = gE.z;
+            }
+            /* V = normalize(eye.origin - pt) raytrace.c:318-320 */
+            Vx = eox - px; Vy = eoy - py; Vz = eoz - pz;
+            normalize3(Vx, Vy, Vz);
+        }
         const uint32_t last = (n_lights - 1u) >> 5;
         for (uint32_t c = 0; c <= last; ++c) {
             uint32_t m = (c == last) ? visible : lds_vis[c * RT_BLOCK + threadIdx.x];
@@ -1189,6 +1206,11 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     const float kr = mC.z, kt = mC.w;
     const bool want_r = !BLINN && hit && (kr != 0.0f) && (level != C.depth); /* raytrace.c:405 */
     const bool want_t = !BLINN && hit && (kt != 0.0f) && (level != C.depth); /* raytrace.c:452 */
+#ifdef RT_ABL_NO_SPAWN /* development ablation: price of everything behind the local colour (wrong pixels) */
+    spawn_r = spawn_t = false;
+    if (hit) { leaf[0] = clamp1(outr); leaf[1] = clamp1(outg); leaf[2] = clamp1(outb); }
+    return false;
+#endif
     spawn_r = want_r;
     spawn_t = want_t;
     if ((BLINN || !GRID) && !(want_r || want_t)) { /* (the older routine never spawns: raytrace.c:683-684) */
@@ -1201,8 +1223,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     }
 
     /* normal (geometry.c:37-57) and V = normalize(eye.origin - pt) (raytrace.c:318-320) again */
-    float Nx, Ny, Nz;
-    {
+    if constexpr (!kFast) {
         const float4 gE = tab[rec + RT_OBJ_SHAPE];
         if (is_sphere) {
             const float nx = px - gE.x, ny = py - gE.y, nz = pz - gE.z;
@@ -1211,9 +1232,9 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
         } else {
             Nx = gE.x; Ny = gE.y; Nz = gE.z;
         }
+        Vx = eox - px; Vy = eoy - py; Vz = eoz - pz;
+        normalize3(Vx, Vy, Vz);
     }
-    float Vx = eox - px, Vy = eoy - py, Vz = eoz - pz;
-    normalize3(Vx, Vy, Vz);
 
     /*
      * The child rays are traced HERE, by the lane that spawns them (get_ray_color's closest-hit
@@ -1294,7 +1315,11 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
             cr.dx = back[3 * RT_BLOCK]; cr.dy = back[4 * RT_BLOCK]; cr.dz = back[5 * RT_BLOCK];
             cr.mag = back[6 * RT_BLOCK];
         }
+#ifdef RT_ABL_NO_CHILD /* development ablation: price of the child searches (wrong pixels) */
+        cobj = RT_NONE;
+#else
         intersect_all<GRID, true, false, STATS, !TABLDS>(S, lds_poly, lds_sph, want, cr, RT_NONE, RT_NONE, cd, cobj, tl);
+#endif
         const bool chit = want && (cobj != RT_NONE);
         if (child == 0u) {
             hit_r = chit;
@@ -1419,22 +1444,36 @@ __device__ __forceinline__ void primary_ray(const float *cam, float fu0, float f
 }
 
 /*
- * Can every sample of one pixel be shown to miss every object?  (Small scenes walk all spheres; big ones
- * test the ball around their grid.)  The samples' un-normalised directions lie within (|U| + |V|) * half a pixel of the
- * pixel centre's (raytrace.c:751-771), so the unit directions d lie within eta of the centre's dc.
+ * What the samples of one pixel can hit, decided conservatively from the pixel's cone of directions.  The
+ * samples' un-normalised directions lie within (|U| + |V|) * half a pixel of the pixel centre's
+ * (raytrace.c:751-771), so the unit directions d lie within eta of the centre's dc.
  *   sphere  (ray.c:186-206) misses when B^2 - 4C < 0, i.e. when the centre's distance |e x d| to the line
  *           exceeds r; |e x d| >= |e x dc| - |e| eta, and a margin of 1e-4 |e|^2 in the squares covers the
- *           float error of either side (1e-6 relative);
+ *           float error of either side (1e-6 relative).  Big scenes test the ball around their grid instead.
  *   polygon (ray.c:92-117) is rejected when w = -(n.o + F) / (n.d) < 0: numerator and denominator of
  *           opposite, exactly known signs - n.d keeps the sign of n.dc when |n.dc| > |n| (eta + 1e-4),
- *           and magnitudes far from underflow keep the quotient's sign.
- * A pixel that passes contributes the background colour for every sample (raytrace.c:700-703), added
- * spp^2 times in the reference's order.  Conservative: `false` just means "trace it".
+ *           and magnitudes far from underflow keep the quotient's sign.  When the signs agree and
+ *           |n.dc| > 4 |n| eta, every sample hits the plane within
+ *               rho = 1.5 * t_c * eta * (1 + |n| / |n.dc|)
+ *           of the centre ray's hit (p(d) - p_c = s [delta - dc (n.delta) / (n.dc)], s <= 4/3 t_c), and the
+ *           polygon's scaled edge equations G_i (edge_screen: G >= 0 deep inside, G <= -1 far outside,
+ *           both with the reference's verdict guaranteed) move by at most gmax * rho, gmax = max_i |grad G_i|
+ *           (host: rt_api.hip).  min G_i(p_c) - gmax rho >= 1e-3: every sample is a hit, accepted by the
+ *           screening stage of the inside test; min G_i(p_c) + gmax rho <= -1 - 1e-3: every sample is rejected by it.
+ * `false` / "unknown" just means "trace it".  Precision of this function itself is irrelevant (hardware
+ * reciprocals and square roots): its margins are a thousand times their error.
  */
+struct PixelView {
+    bool spheres;     /* some sphere may be hit by some sample                                          */
+    bool unsure;      /* some polygon may or may not be hit                                             */
+    uint32_t inside;  /* polygon that EVERY sample hits, inside for sure (RT_NONE: none; two such: unsure) */
+};
 template <bool GRID>
-__device__ __forceinline__ bool pixel_sees_nothing(const DevScene &S, const float *cam, const float4 *lds_poly,
-                                                   const float4 *lds_sph, float fu0, float fv0, uint32_t sqrtSpp)
+__device__ __forceinline__ PixelView classify_pixel(const DevScene &S, const float *cam, const float4 *lds_poly,
+                                                    const float4 *lds_sph, float fu0, float fv0, uint32_t sqrtSpp)
 {
+    PixelView pv;
+    pv.spheres = true; pv.unsure = true; pv.inside = RT_NONE;
     const float half = 0.5f * (float)sqrtSpp * cam[CAM_SPPW];
     const float fu = fu0 + half, fv = fv0 + half;
     const float Dx = (cam[CAM_SHIFTN + 0] + cam[CAM_U + 0] * fu) + cam[CAM_V + 0] * fv;
@@ -1442,16 +1481,17 @@ __device__ __forceinline__ bool pixel_sees_nothing(const DevScene &S, const floa
     const float Dz = (cam[CAM_SHIFTN + 2] + cam[CAM_U + 2] * fu) + cam[CAM_V + 2] * fv;
     const float D2 = dot3(Dx, Dy, Dz, Dx, Dy, Dz);
     if (!(D2 > 1e-20f))
-        return false;
-    const float invD = 1.0f / sqrtf(D2);
+        return pv;
+    const float invD = __builtin_amdgcn_rsqf(D2);
     const float dcx = Dx * invD, dcy = Dy * invD, dcz = Dz * invD;
-    const float lenU = sqrtf(dot3(cam[CAM_U + 0], cam[CAM_U + 1], cam[CAM_U + 2], cam[CAM_U + 0], cam[CAM_U + 1], cam[CAM_U + 2]));
-    const float lenV = sqrtf(dot3(cam[CAM_V + 0], cam[CAM_V + 1], cam[CAM_V + 2], cam[CAM_V + 0], cam[CAM_V + 1], cam[CAM_V + 2]));
+    const float lenU = __builtin_amdgcn_sqrtf(dot3(cam[CAM_U + 0], cam[CAM_U + 1], cam[CAM_U + 2], cam[CAM_U + 0], cam[CAM_U + 1], cam[CAM_U + 2]));
+    const float lenV = __builtin_amdgcn_sqrtf(dot3(cam[CAM_V + 0], cam[CAM_V + 1], cam[CAM_V + 2], cam[CAM_V + 0], cam[CAM_V + 1], cam[CAM_V + 2]));
     /* |d - dc| <= |D - Dc| / |Dc| for unit vectors made from D, Dc (times 1 / (1 - x/2) <= 1.13 for the x < 0.22 admitted below) */
     const float eta = 1.15f * ((lenU + lenV) * fabsf(half)) * invD + 1e-6f;
     if (!(eta < 0.25f))
-        return false;
+        return pv;
     const float ox = cam[CAM_EYE + 0], oy = cam[CAM_EYE + 1], oz = cam[CAM_EYE + 2];
+    bool spheres = false;
     if constexpr (GRID) {
         /* Big scenes: one test against the ball around the grid's box, which holds every sphere whole.  A
          * line that misses the ball by delta misses sphere k by delta as well, but for a small sphere
@@ -1459,36 +1499,57 @@ __device__ __forceinline__ bool pixel_sees_nothing(const DevScene &S, const floa
          * 2.5e-5 |e_k|^2, six times the float error of the reference's discriminant. */
         const GridHeader &G = *(const GridHeader *)S.grid;
         const float bx = G.gmax[0] - G.gmin[0], by = G.gmax[1] - G.gmin[1], bz = G.gmax[2] - G.gmin[2];
-        const float R = 0.5f * sqrtf(dot3(bx, by, bz, bx, by, bz)) * 1.001f;
+        const float R = 0.5f * __builtin_amdgcn_sqrtf(dot3(bx, by, bz, bx, by, bz)) * 1.001f;
         const float ex = ox - G.centre[0], ey = oy - G.centre[1], ez = oz - G.centre[2];
         const float e2 = dot3(ex, ey, ez, ex, ey, ez);
         const float t = dot3(ex, ey, ez, dcx, dcy, dcz);
-        const float E = sqrtf(e2);
-        const float m = sqrtf(fmaxf(e2 - t * t, 0.0f)) - E * eta;
-        if (!(m > R + 5e-3f * (E + R)))
-            return false;
+        const float E = __builtin_amdgcn_sqrtf(e2);
+        const float m = __builtin_amdgcn_sqrtf(fmaxf(e2 - t * t, 0.0f)) - E * eta;
+        spheres = !(m > R + 5e-3f * (E + R));
     }
     for (uint32_t k = 0; k < (GRID ? 0u : S.nSph); ++k) {
         const float4 sp = lds_sph[k]; /* (centre, r^2) */
         const float ex = ox - sp.x, ey = oy - sp.y, ez = oz - sp.z;
         const float e2 = dot3(ex, ey, ez, ex, ey, ez);
         const float t = dot3(ex, ey, ez, dcx, dcy, dcz);
-        const float rho = sqrtf(fmaxf(e2 - t * t, 0.0f));
-        const float m = rho - sqrtf(e2) * eta;
-        if (!(m > 0.0f && m * m > sp.w + 1e-4f * e2 + 1e-30f))
-            return false;
+        const float rho = __builtin_amdgcn_sqrtf(fmaxf(e2 - t * t, 0.0f));
+        const float m = rho - __builtin_amdgcn_sqrtf(e2) * eta * 1.0001f;
+        spheres = spheres || !(m > 0.0f && m * m > sp.w + 1e-4f * e2 + 1e-30f);
     }
+    bool unsure = false;
+    uint32_t inside = RT_NONE;
     for (uint32_t k = 0; k < S.nPoly; ++k) {
         const float4 pl = lds_poly[k]; /* (A, B, C, F) */
         const float num = -1.0f * (dot3(pl.x, pl.y, pl.z, ox, oy, oz) + pl.w);
         const float q = dot3(pl.x, pl.y, pl.z, dcx, dcy, dcz);
-        const float nlen = sqrtf(dot3(pl.x, pl.y, pl.z, pl.x, pl.y, pl.z));
-        const bool behind = fabsf(q) > nlen * (eta + 1e-4f) && fabsf(q) < 1e10f && fabsf(num) > 1e-20f &&
-                            fabsf(num) < 1e10f && ((num > 0.0f) != (q > 0.0f));
-        if (!behind)
-            return false;
+        const float nlen = __builtin_amdgcn_sqrtf(dot3(pl.x, pl.y, pl.z, pl.x, pl.y, pl.z)) * 1.0001f;
+        const bool sane = fabsf(q) < 1e10f && fabsf(num) > 1e-20f && fabsf(num) < 1e10f;
+        const bool opposite = (num > 0.0f) != (q > 0.0f);
+        if (sane && opposite && fabsf(q) > nlen * (eta + 1e-4f))
+            continue; /* behind the eye for every sample */
+        int verdict = 0; /* +1: every sample inside, -1: every sample outside */
+        if (sane && !opposite && fabsf(q) > nlen * (4.0f * eta + 1e-4f)) {
+            const float4 info = lds_poly[S.nPoly + k];
+            const uint32_t nv = __float_as_uint(info.y);
+            const float4 *edg = lds_poly + 2 * S.nPoly + __float_as_uint(info.x) + ((S.nPolySlots - 2u * S.nPoly) >> 1);
+            const float tc = num * __builtin_amdgcn_rcpf(q);
+            const float pcx = ox + dcx * tc, pcy = oy + dcy * tc, pcz = oz + dcz * tc;
+            float gmin = 3.0e38f;
+            for (uint32_t i = 0; i < nv; ++i)
+                gmin = fminf(gmin, edge_value(edg[i], pcx, pcy, pcz));
+            const float rho = 1.5f * tc * eta * (1.0f + nlen * __builtin_amdgcn_rcpf(fabsf(q)));
+            const float move = info.w * rho + 1e-3f; /* info.w = gmax */
+            verdict = (gmin - move >= 0.0f) ? 1 : ((gmin + move <= -1.0f) ? -1 : 0);
+        }
+        if (verdict < 0)
+            continue;
+        if (verdict > 0 && inside == RT_NONE)
+            inside = k;
+        else
+            unsure = true;
     }
-    return true;
+    pv.spheres = spheres; pv.unsure = unsure; pv.inside = inside;
+    return pv;
 }
 
 /* Where shade_and_spawn gets the eye ray back from after the shadow rays (see there).  The empty
@@ -1617,7 +1678,8 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
     /* a wave owns an 8x8 pixel tile; the block is 4 tiles side by side (32x8 pixels) */
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t x = blockIdx.x * 32u + wv * 8u + (lane & 7u);
-    const uint32_t y = R.y_first + blockIdx.y * R.y_step + (lane >> 3);
+    const uint32_t ty = blockIdx.y; /* (tile rows top-down: centre-out, bottom-up and alternating orders all measured slower) */
+    const uint32_t y = R.y_first + ty * R.y_step + (lane >> 3);
     const bool valid = (x < C.W) && (y < R.y_limit);
 
     /* raytrace.c:755-763: the pixel-dependent part of the U and V shifts */
@@ -1625,13 +1687,13 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
     const float fv0 = ((C.hfbH - (float)y) / C.hfbH) * C.halfH;
 
     /* every wave feeds its own shard: even a single tile row spreads over all of them */
-    const uint32_t shard = ((blockIdx.y * gridDim.x + blockIdx.x) * (RT_BLOCK / 64u) +
+    const uint32_t shard = ((ty * gridDim.x + blockIdx.x) * (RT_BLOCK / 64u) +
                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) % RT_SHARDS;
     const uint32_t node_base = shard * Wk.capS; /* level 0 opens every shard's node range */
 
     float accr = 0.0f, accg = 0.0f, accb = 0.0f; /* color_init raytrace.c:908 */
     uint32_t nroots = 0; /* samples of this pixel that became tree roots */
-    const size_t pix = (size_t)(blockIdx.y * 8u + (lane >> 3)) * C.W + x; /* pixel of the batch */
+    const size_t pix = (size_t)(ty * 8u + (lane >> 3)) * C.W + x; /* pixel of the batch */
     const size_t pix_stride = (size_t)R.ntiles * 8u * C.W;
     SpawnCounts sc;
     Tally<STATS> tl;
@@ -1640,8 +1702,19 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
     /* A tile none of whose pixels can see anything (sky: 40 % of the tiles of the reference's scene) is
      * finished without tracing: spp^2 times the background colour, added in the reference's order.  The
      * instrumented kernels trace everything (they count the reference's tests). */
+    bool tile_no_spheres = false;    /* wave-uniform: no sample of the tile can meet a sphere */
+    uint32_t tile_polygon = RT_NONE; /* wave-uniform: every sample of the tile hits this polygon and nothing else */
     if constexpr (!STATS) {
-        const bool nothing = !valid || pixel_sees_nothing<GRID>(S, cam, lds_poly, lds_sph, fu0, fv0, C.sqrtSpp);
+        const PixelView pv = classify_pixel<GRID>(S, cam, lds_poly, lds_sph, fu0, fv0, C.sqrtSpp);
+        const bool nothing = !valid || (!pv.spheres && !pv.unsure && pv.inside == RT_NONE);
+        tile_no_spheres = __all(!valid || !pv.spheres);
+        if constexpr (kFast && !BLINN) {
+            /* (the tolerance build only: the hit point is formed without normalising the direction) */
+            const unsigned long long live = __ballot(valid);
+            const uint32_t first = live ? (uint32_t)__builtin_amdgcn_readlane((int)pv.inside, __ffsll((long long)live) - 1) : RT_NONE;
+            if (tile_no_spheres && first != RT_NONE && __all(!valid || (pv.inside == first && !pv.unsure)))
+                tile_polygon = first;
+        }
         if (__all(nothing)) { /* wave-uniform; no barrier follows */
             for (uint32_t k = 0; k < C.sqrtSpp * C.sqrtSpp; ++k) {
                 accr = accr + kc[KC_BG + 0];
@@ -1656,18 +1729,35 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
 
     for (uint32_t j = 0; j < C.sqrtSpp; ++j) {
         for (uint32_t i = 0; i < C.sqrtSpp; ++i) {
-            Ray r;
-            primary_ray(cam, fu0, fv0, i, j, r);
-
-            float d;
+            float px, py, pz;
             uint32_t obj;
-            intersect_all<GRID, false, false, STATS, !TABLDS, TABLDS>(S, lds_poly, lds_sph, valid, r, RT_NONE,
-                                                              RT_NONE, d, obj, tl, eye_terms);
+            if (kFast && tile_polygon != RT_NONE) {
+                /* every sample of this tile hits polygon tile_polygon, inside, and nothing else: the hit
+                 * point is eye + D * (num / n.D) with the un-normalised direction D (raytrace.c:751-768,
+                 * ray.c:92-122 without the detour over the unit vector) */
+                const float fv = fv0 + (cam[CAM_SPPHALF] + (float)j * cam[CAM_SPPW]);
+                const float fu = fu0 + (cam[CAM_SPPHALF] + (float)i * cam[CAM_SPPW]);
+                const float Dx = (cam[CAM_SHIFTN + 0] + cam[CAM_U + 0] * fu) + cam[CAM_V + 0] * fv;
+                const float Dy = (cam[CAM_SHIFTN + 1] + cam[CAM_U + 1] * fu) + cam[CAM_V + 1] * fv;
+                const float Dz = (cam[CAM_SHIFTN + 2] + cam[CAM_U + 2] * fu) + cam[CAM_V + 2] * fv;
+                const float4 pl = lds_poly[tile_polygon];
+                const float ox = cam[CAM_EYE + 0], oy = cam[CAM_EYE + 1], oz = cam[CAM_EYE + 2];
+                const float num = -1.0f * (dot3(pl.x, pl.y, pl.z, ox, oy, oz) + pl.w);
+                const float t = num * rcp_refined(dot3(pl.x, pl.y, pl.z, Dx, Dy, Dz));
+                px = ox + Dx * t; py = oy + Dy * t; pz = oz + Dz * t;
+                obj = __float_as_uint(lds_poly[S.nPoly + tile_polygon].z);
+            } else {
+                Ray r;
+                primary_ray(cam, fu0, fv0, i, j, r);
+                float d;
+                intersect_all<GRID, false, false, STATS, !TABLDS, TABLDS>(S, lds_poly, lds_sph, valid, r, RT_NONE,
+                                                                  RT_NONE, d, obj, tl, eye_terms, tile_no_spheres);
+                px = r.ox + r.dx * d; py = r.oy + r.dy * d; pz = r.oz + r.dz * d;
+            }
             const bool hit = valid && (obj != RT_NONE);
             float leaf[3] = {kc[KC_BG + 0], kc[KC_BG + 1], kc[KC_BG + 2]}; /* miss: raytrace.c:700-703 */
             uint32_t node;
             bool sr, st_;
-            const float px = r.ox + r.dx * d, py = r.oy + r.dy * d, pz = r.oz + r.dz * d;
             const PrimaryEye eye_src{cam, fu0, fv0, i, j};
             bool deferred = shade_and_spawn<GRID, STATS, TABLDS, BLINN>(S, C, Wk, lds_poly, lds_sph, lds_vis, lds_park, kc, tab, hit,
                                                           eye_src, px, py, pz, obj, 0u, RT_LINK_NONE << 3, shard,
