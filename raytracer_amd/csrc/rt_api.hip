@@ -307,13 +307,7 @@ uint32_t tiles_per_batch(const rt_hip_ctx *c, uint64_t max_samples)
     return (uint32_t)(t > 0x0FFFFFFFull ? 0x0FFFFFFFull : t);
 }
 
-bool batch_overflowed(const uint32_t *cnt)
-{
-    for (int l = 0; l < RT_MAX_LEVELS; ++l)
-        if (cnt[CNT_OVERFLOW + l])
-            return true;
-    return false;
-}
+bool batch_overflowed(const uint32_t *cnt) { return cnt[CNT_OVERFLOW] != 0u; } /* one flag per batch: rt_device.h */
 
 /* remember how full the level queues / node ranges of a batch got (grid sizing of the next one) */
 void note_levels(rt_hip_ctx *c, const uint32_t *cnt, uint32_t levels, bool first, uint64_t samples)

@@ -137,7 +137,9 @@ struct DevWork {
 };
 
 /*
- * Counter block (uint32 words, zeroed per batch by hipMemsetAsync).
+ * Counter block of a batch (uint32 words).  Zero when a batch starts: k_publish, the last kernel of every
+ * batch, copies the block to the host's mapped mirror and zeroes it for its next use (the host clears
+ * the blocks once at context creation, and again only after a render died midway).
  *
  * Queues and the node pool are split into RT_SHARDS shards, each with its own counters on its
  * own 128-byte line: one L2 word sustains only ~90 returning atomics per microsecond on MI355X,
@@ -145,10 +147,11 @@ struct DevWork {
  * the whole frame (measured: 1.6 ms -> see DESIGN.md).  A block produces into / consumes from
  * shard (block index % RT_SHARDS).
  *
- *   word L (L < RT_MAX_LEVELS)  : overflow flag raised by the kernel that processes level L;
- *                                 every later kernel of the batch returns at once when one is
- *                                 set (slots reserved by an overflowing wave stay unwritten, so
- *                                 nothing downstream may consume the queues)
+ *   word CNT_OVERFLOW (0)       : ONE overflow flag for the whole batch, raised by any kernel whose
+ *                                 reservation did not fit; every later kernel of the batch returns at
+ *                                 once when it is set (slots reserved by an overflowing wave stay
+ *                                 unwritten, so nothing downstream may consume the queues) and the host
+ *                                 renders the batch again in two halves.  Words 1 .. RT_MAX_LEVELS-1 are spare.
  *   CNT_STATS + s*64            : uint64 statistics of shard s (ST_* slots)
  *   CNT_LEVELS + (L*RT_SHARDS+s)*RT_LINE_WORDS : one uint64 for (level L, shard s):
  *                                 low 32 bits  = tree nodes made at level L

@@ -27,6 +27,7 @@
  */
 #include "rt_device.h"
 #include "rt_arith.h"
+#include "rt_dev.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -98,34 +99,6 @@ template <> struct Tally<true> {
 };
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
-
-/* Development build (-DRT_PHASE_CLOCKS, tools/phase_probe.py): wave cycles per phase of k_bounce,
- * read with s_memtime, summed into the statistic slots the
- * plain build leaves unused (ST_SPH_TESTS + phase).  Compiles to nothing otherwise. */
-struct PhaseClock {
-#ifdef RT_PHASE_CLOCKS
-    unsigned long long last = 0, acc[10] = {};
-    /* the clock read waits for outstanding LDS / scalar loads only: vector-memory stalls are charged
-     * to the phase whose instructions actually wait for them, as in the plain build */
-    __device__ __forceinline__ void start() { last = clock64(); }
-    __device__ __forceinline__ void mark(int k)
-    {
-        const unsigned long long t = clock64();
-        acc[k] += t - last;
-        last = t;
-    }
-    __device__ __forceinline__ void flush(uint64_t *st)
-    {
-        if (lane_id() == 0)
-            for (int k = 0; k < 10; ++k)
-                atomicAdd((unsigned long long *)&st[ST_SPH_TESTS + k], acc[k]);
-    }
-#else
-    __device__ __forceinline__ void start() {}
-    __device__ __forceinline__ void mark(int) {}
-    __device__ __forceinline__ void flush(uint64_t *) {}
-#endif
-};
 
 /* sum a per-lane counter over the wave and add it to a 64-bit global statistic */
 __device__ __forceinline__ void wave_add_stat(uint64_t *stats, int slot, uint32_t v)
@@ -419,19 +392,14 @@ template <bool STATS, bool QUAD>
 __device__ __forceinline__ bool polygon_inside(const float4 *vtx, const float4 *edg, uint32_t nv,
                                                float px, float py, float pz, Tally<STATS> &tl)
 {
-#ifdef RT_ABL_NO_ANGLESUM /* development ablation: price of the inside test (wrong pixels) */
-    return px > -15.0f && px < 7.0f && pz > -100.0f && pz < 0.0f;
-#endif
+    RT_DEV_NO_ANGLESUM(px, pz);
     const bool quad = QUAD && nv == 4u;
     const int s = quad ? edge_screen_quad(edg, px, py, pz) : edge_screen(edg, nv, px, py, pz);
     if constexpr (!STATS) {
         if (s != 0)
             return s > 0;
     }
-#ifdef RT_ABL_NO_BAND /* development ablation: price of stages 2-3 (wrong pixels along polygon edges) */
-    if (!STATS)
-        return false;
-#endif
+    RT_DEV_NO_BAND(STATS);
     const bool e = quad ? quad_inside_exact(quad_edges(vtx, px, py, pz)) : polygon_inside_exact(vtx, nv, px, py, pz);
     if constexpr (STATS) {
         if (s != 0 && (s > 0) != e)
@@ -956,7 +924,7 @@ __device__ __forceinline__ void wave_reserve(unsigned long long *line, bool want
     const int leader = __ffsll((long long)m) - 1;
     const uint32_t nr = __popcll(mr), nt = __popcll(mt);
     unsigned long long old = 0;
-    if ((int)lane == leader)
+    if (RT_DEV_ATOMIC((int)lane == leader))
         old = atomicAdd(line, (unsigned long long)__popcll(m) | ((unsigned long long)(nr + nt) << 32));
     const uint32_t old_lo = __shfl((uint32_t)old, leader, 64);
     const uint32_t old_hi = __shfl((uint32_t)(old >> 32), leader, 64);
@@ -1027,8 +995,10 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
                                                 uint32_t link, uint32_t shard, uint32_t node_base,
                                                 uint32_t node_room, float leaf[3], uint32_t &node_idx,
                                                 bool &spawn_r, bool &spawn_t, Tally<STATS> &tl,
-                                                PhaseClock &pc)
+                                                PhaseClock &pc, bool all_lit = false)
 {
+    /* all_lit (wave-uniform): the caller has shown that no shadow ray of this wave's hits can meet anything
+     * (classify_pixel: one polygon in the scene, every sphere clear of every line from a hit to a light) */
     node_idx = RT_NONE;
     spawn_r = spawn_t = false;
     if (!GRID && !hit)
@@ -1053,14 +1023,12 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     }
 
     float dfr = 0.f, dfg = 0.f, dfb = 0.f, spr = 0.f, spg = 0.f, spb = 0.f;
-#ifdef RT_ABL_NO_LIGHTS /* development ablation: price of shadow rays + Phong (wrong pixels) */
-    const uint32_t n_lights = 0;
-#else
-    const uint32_t n_lights = S.nLights;
-#endif
+    const uint32_t n_lights = RT_DEV_LIGHTS(S.nLights);
     /* pass A (raytrace.c:327-347).  Visibility words of all but the last 32 lights go to LDS. */
     uint32_t visible = 0;
-    for (uint32_t l = 0; l < n_lights; ++l) {
+    if (all_lit) /* (at most 32 lights: the caller's condition) */
+        visible = hit ? (n_lights >= 32u ? 0xFFFFFFFFu : (1u << n_lights) - 1u) : 0u;
+    for (uint32_t l = 0; l < (all_lit ? 0u : n_lights); ++l) {
         const float4 lp = tab[2u * l];
         /* ray_create(pt, light) ray.c:29-41 */
         Ray sh;
@@ -1134,7 +1102,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
                 const float4 lp = tab[2u * l];
                 const float4 lc = tab[2u * l + 1u];
                 float sx, sy, sz;
-                if (n_lights == 1u) { /* parked by pass A: the same expressions, hence the same values */
+                if (n_lights == 1u && !all_lit) { /* parked by pass A: the same expressions, hence the same values */
                     uint32_t t = threadIdx.x;
                     asm volatile("" : "+v"(t));
                     const float *back = lds_park + t;
@@ -1206,11 +1174,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     const float kr = mC.z, kt = mC.w;
     const bool want_r = !BLINN && hit && (kr != 0.0f) && (level != C.depth); /* raytrace.c:405 */
     const bool want_t = !BLINN && hit && (kt != 0.0f) && (level != C.depth); /* raytrace.c:452 */
-#ifdef RT_ABL_NO_SPAWN /* development ablation: price of everything behind the local colour (wrong pixels) */
-    spawn_r = spawn_t = false;
-    if (hit) { leaf[0] = clamp1(outr); leaf[1] = clamp1(outg); leaf[2] = clamp1(outb); }
-    return false;
-#endif
+    RT_DEV_NO_SPAWN(hit, leaf, outr, outg, outb, spawn_r, spawn_t);
     spawn_r = want_r;
     spawn_t = want_t;
     if ((BLINN || !GRID) && !(want_r || want_t)) { /* (the older routine never spawns: raytrace.c:683-684) */
@@ -1301,6 +1265,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
         park[6 * RT_BLOCK] = tr.mag;
         park[17 * RT_BLOCK] = outr; park[18 * RT_BLOCK] = outg; park[19 * RT_BLOCK] = outb;
     }
+    pc.mark(8);
     bool hit_r = false, hit_t = false;
     float cd = 0.0f;
     uint32_t cobj = RT_NONE;
@@ -1315,11 +1280,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
             cr.dx = back[3 * RT_BLOCK]; cr.dy = back[4 * RT_BLOCK]; cr.dz = back[5 * RT_BLOCK];
             cr.mag = back[6 * RT_BLOCK];
         }
-#ifdef RT_ABL_NO_CHILD /* development ablation: price of the child searches (wrong pixels) */
-        cobj = RT_NONE;
-#else
-        intersect_all<GRID, true, false, STATS, !TABLDS>(S, lds_poly, lds_sph, want, cr, RT_NONE, RT_NONE, cd, cobj, tl);
-#endif
+        intersect_all<GRID, true, false, STATS, !TABLDS>(S, lds_poly, lds_sph, RT_DEV_CHILD(want), cr, RT_NONE, RT_NONE, cd, cobj, tl);
         const bool chit = want && (cobj != RT_NONE);
         if (child == 0u) {
             hit_r = chit;
@@ -1334,6 +1295,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
             hit_t = chit;
         }
     }
+    pc.mark(9);
     if (!hit)
         return false;
     float kr2, kt2;
@@ -1467,13 +1429,17 @@ struct PixelView {
     bool spheres;     /* some sphere may be hit by some sample                                          */
     bool unsure;      /* some polygon may or may not be hit                                             */
     uint32_t inside;  /* polygon that EVERY sample hits, inside for sure (RT_NONE: none; two such: unsure) */
+    bool lit;         /* (with `inside`) no shadow ray from any of those hits can meet a sphere: a sphere at
+                         more than its radius + the footprint's radius from the line (centre hit, light) is
+                         missed by every line (hit, light) - with the margin of the sphere test above        */
 };
-template <bool GRID>
+template <bool GRID, bool TABLDS>
 __device__ __forceinline__ PixelView classify_pixel(const DevScene &S, const float *cam, const float4 *lds_poly,
-                                                    const float4 *lds_sph, float fu0, float fv0, uint32_t sqrtSpp)
+                                                    const float4 *lds_sph, const Tables<TABLDS> &tab, float fu0,
+                                                    float fv0, uint32_t sqrtSpp)
 {
     PixelView pv;
-    pv.spheres = true; pv.unsure = true; pv.inside = RT_NONE;
+    pv.spheres = true; pv.unsure = true; pv.inside = RT_NONE; pv.lit = false;
     const float half = 0.5f * (float)sqrtSpp * cam[CAM_SPPW];
     const float fu = fu0 + half, fv = fv0 + half;
     const float Dx = (cam[CAM_SHIFTN + 0] + cam[CAM_U + 0] * fu) + cam[CAM_V + 0] * fv;
@@ -1516,7 +1482,7 @@ __device__ __forceinline__ PixelView classify_pixel(const DevScene &S, const flo
         const float m = rho - __builtin_amdgcn_sqrtf(e2) * eta * 1.0001f;
         spheres = spheres || !(m > 0.0f && m * m > sp.w + 1e-4f * e2 + 1e-30f);
     }
-    bool unsure = false;
+    bool unsure = false, lit = false;
     uint32_t inside = RT_NONE;
     for (uint32_t k = 0; k < S.nPoly; ++k) {
         const float4 pl = lds_poly[k]; /* (A, B, C, F) */
@@ -1540,6 +1506,23 @@ __device__ __forceinline__ PixelView classify_pixel(const DevScene &S, const flo
             const float rho = 1.5f * tc * eta * (1.0f + nlen * __builtin_amdgcn_rcpf(fabsf(q)));
             const float move = info.w * rho + 1e-3f; /* info.w = gmax */
             verdict = (gmin - move >= 0.0f) ? 1 : ((gmin + move <= -1.0f) ? -1 : 0);
+            if (kFast && !GRID && verdict > 0 && inside == RT_NONE) { /* shadow rays of this polygon's hits */
+                lit = true;
+                for (uint32_t l = 0; l < S.nLights; ++l) {
+                    const float4 lp = tab[2u * l];
+                    const float lx = lp.x - pcx, ly = lp.y - pcy, lz = lp.z - pcz;
+                    const float il = __builtin_amdgcn_rsqf(dot3(lx, ly, lz, lx, ly, lz));
+                    const float ux = lx * il, uy = ly * il, uz = lz * il;
+                    for (uint32_t j = 0; j < S.nSph; ++j) {
+                        const float4 sp = lds_sph[j];
+                        const float ex = sp.x - pcx, ey = sp.y - pcy, ez = sp.z - pcz;
+                        const float e2 = dot3(ex, ey, ez, ex, ey, ez);
+                        const float t = dot3(ex, ey, ez, ux, uy, uz);
+                        const float m = __builtin_amdgcn_sqrtf(fmaxf(e2 - t * t, 0.0f)) - (1.01f * rho + 2e-3f);
+                        lit = lit && (m > 0.0f && m * m > sp.w + 1e-4f * e2 + 1e-30f);
+                    }
+                }
+            }
         }
         if (verdict < 0)
             continue;
@@ -1548,7 +1531,7 @@ __device__ __forceinline__ PixelView classify_pixel(const DevScene &S, const flo
         else
             unsure = true;
     }
-    pv.spheres = spheres; pv.unsure = unsure; pv.inside = inside;
+    pv.spheres = spheres; pv.unsure = unsure; pv.inside = inside; pv.lit = lit;
     return pv;
 }
 
@@ -1697,23 +1680,26 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
     const size_t pix_stride = (size_t)R.ntiles * 8u * C.W;
     SpawnCounts sc;
     Tally<STATS> tl;
-    PhaseClock pc; /* unused here */
+    PhaseClock pc; /* (development builds: cycles per phase of a sample, tools/phase_probe_k0.py) */
 
     /* A tile none of whose pixels can see anything (sky: 40 % of the tiles of the reference's scene) is
      * finished without tracing: spp^2 times the background colour, added in the reference's order.  The
      * instrumented kernels trace everything (they count the reference's tests). */
     bool tile_no_spheres = false;    /* wave-uniform: no sample of the tile can meet a sphere */
     uint32_t tile_polygon = RT_NONE; /* wave-uniform: every sample of the tile hits this polygon and nothing else */
+    bool tile_lit = false;           /* wave-uniform: ... and no shadow ray from those hits can meet anything   */
     if constexpr (!STATS) {
-        const PixelView pv = classify_pixel<GRID>(S, cam, lds_poly, lds_sph, fu0, fv0, C.sqrtSpp);
+        const PixelView pv = classify_pixel<GRID, TABLDS>(S, cam, lds_poly, lds_sph, tab, fu0, fv0, C.sqrtSpp);
         const bool nothing = !valid || (!pv.spheres && !pv.unsure && pv.inside == RT_NONE);
         tile_no_spheres = __all(!valid || !pv.spheres);
         if constexpr (kFast && !BLINN) {
             /* (the tolerance build only: the hit point is formed without normalising the direction) */
             const unsigned long long live = __ballot(valid);
             const uint32_t first = live ? (uint32_t)__builtin_amdgcn_readlane((int)pv.inside, __ffsll((long long)live) - 1) : RT_NONE;
-            if (tile_no_spheres && first != RT_NONE && __all(!valid || (pv.inside == first && !pv.unsure)))
+            if (tile_no_spheres && first != RT_NONE && __all(!valid || (pv.inside == first && !pv.unsure))) {
                 tile_polygon = first;
+                tile_lit = S.nPoly == 1u && S.nLights <= 32u && __all(!valid || pv.lit);
+            }
         }
         if (__all(nothing)) { /* wave-uniform; no barrier follows */
             for (uint32_t k = 0; k < C.sqrtSpp * C.sqrtSpp; ++k) {
@@ -1731,6 +1717,7 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
         for (uint32_t i = 0; i < C.sqrtSpp; ++i) {
             float px, py, pz;
             uint32_t obj;
+            pc.start();
             if (kFast && tile_polygon != RT_NONE) {
                 /* every sample of this tile hits polygon tile_polygon, inside, and nothing else: the hit
                  * point is eye + D * (num / n.D) with the un-normalised direction D (raytrace.c:751-768,
@@ -1754,6 +1741,7 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
                                                                   RT_NONE, d, obj, tl, eye_terms, tile_no_spheres);
                 px = r.ox + r.dx * d; py = r.oy + r.dy * d; pz = r.oz + r.dz * d;
             }
+            pc.mark(0);
             const bool hit = valid && (obj != RT_NONE);
             float leaf[3] = {kc[KC_BG + 0], kc[KC_BG + 1], kc[KC_BG + 2]}; /* miss: raytrace.c:700-703 */
             uint32_t node;
@@ -1761,7 +1749,7 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
             const PrimaryEye eye_src{cam, fu0, fv0, i, j};
             bool deferred = shade_and_spawn<GRID, STATS, TABLDS, BLINN>(S, C, Wk, lds_poly, lds_sph, lds_vis, lds_park, kc, tab, hit,
                                                           eye_src, px, py, pz, obj, 0u, RT_LINK_NONE << 3, shard,
-                                                          node_base, Wk.capS, leaf, node, sr, st_, tl, pc);
+                                                          node_base, Wk.capS, leaf, node, sr, st_, tl, pc, tile_lit);
             sc.add(hit, sr, st_);
             /* The reference adds a pixel's samples in order (raytrace.c:774) and float addition does
              * not commute: a finished sample that FOLLOWS a root of its pixel must be added after
@@ -1785,12 +1773,14 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
                 accg = accg + leaf[1];
                 accb = accb + leaf[2];
             }
+            pc.mark(7);
         }
     }
     if (valid)
         Wk.pixAcc[pix] = make_float4(accr, accg, accb, __uint_as_float(nroots));
 
     uint64_t *st = (uint64_t *)(Wk.counters + CNT_STATS + shard * CNT_STATS_STRIDE);
+    pc.flush(st);
     wave_add_total(st, ST_K0_SHADE_NODES, sc.shade_nodes);
     wave_add_total(st, ST_K0_REFL, sc.refl);
     wave_add_total(st, ST_K0_TRANS, sc.trans);

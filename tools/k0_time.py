@@ -5,8 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import raytracer_amd as rt
 mode = rt.NUMERICS_EXACT if "exact" in sys.argv[1:] else rt.NUMERICS_FAST
-W, H, s, d = 1920, 1080, 4, 8
+W, H, s, d = [int(v) for v in os.environ.get("K0_FRAME", "1920,1080,4,8").split(",")]
 ROW0 = int(os.environ.get("K0_ROW0", "0"))
+NROWS = int(os.environ.get("K0_NROWS", "0")) or None
 sc = rt.Scene.builtin()
 cam = rt.prepare_camera(sc, W, H, s, d)
 
@@ -18,12 +19,12 @@ def run(mode, frames):
     argb = torch.zeros((H, W), dtype=torch.int32, device="cuda")
     rad = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
     for _ in range(30):
-        ctx.render_rows(cam, argb.data_ptr(), rad.data_ptr(), ROW0, H - ROW0); st = ctx.finish()
+        ctx.render_rows(cam, argb.data_ptr(), rad.data_ptr(), ROW0, NROWS or H - ROW0); st = ctx.finish()
     ctx.set_timing(True)
     k0, n = 0.0, 0
     t0 = time.perf_counter()
     for _ in range(frames):
-        ctx.render_rows(cam, argb.data_ptr(), rad.data_ptr(), ROW0, H - ROW0); st = ctx.finish()
+        ctx.render_rows(cam, argb.data_ptr(), rad.data_ptr(), ROW0, NROWS or H - ROW0); st = ctx.finish()
         k0 += st.k0_ms; n += st.k0_launches
     dt = (time.perf_counter() - t0) / frames
     rays = st.primary_rays + st.shadow_rays + st.reflection_rays + st.transmission_rays
