@@ -1,22 +1,34 @@
 #!/usr/bin/env python3
-"""bench.py - throughput of the HIP trace-and-shade path on BASELINE.json's headline workload.
+"""bench.py - throughput of the HIP trace-and-shade path on BASELINE.json's workloads.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5s|c1] [--scaling strong|weak]
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one full render of the frame: every rank renders its row share with the scene and the
-frame buffer resident in HBM, then (N > 1) the frame-buffer slices are collected with one RCCL
-all-gather.  N = 1 renders BASELINE config 2 (builtin Whitted scene, 1920x1080, 4x4 supersampling,
-depth 8).  N > 1 keeps the per-GPU work fixed (weak scaling): the frame grows to N x the pixels at
-16:9 (N = 4 is BASELINE config 3, 3840x2160).
+A "step" is one full render of the frame: every rank renders its row share with the scene and the frame
+buffer resident in HBM, then (N > 1) the frame-buffer slices are collected with one RCCL all-gather.
 
-Rank 0 prints ONE JSON line.  `value` = rays (primary + shadow + reflection + transmission, counted
-by the kernels) of all ranks / max-over-ranks time.  `roofline` prices the dominant kernel
-(k_primary) with the algorithmic FLOP constants of SURVEY.md section 8d against the FP32 vector peak;
-`cpu_baseline` times the reference (or the oracle port) on one host core.
+Workloads (BASELINE.json `configs`):
+    c2   builtin Whitted scene 1920x1080, 4x4 supersampling, depth 8     the N = 1 default (the metric's config)
+    c3   the same scene at 3840x2160                                      the N > 1 default: a FIXED frame split
+                                                                          over the ranks ("strong" scaling), as
+                                                                          the reference's Cell build splits one
+                                                                          image over its workers
+    c1   640x480, 1 spp, depth 4 (the reference's CPU-runnable case)
+    c4   1024 random spheres + 4 quads, 3840x2160, 16 spp, depth 8
+    c5s  the scene of config 5 (16 384 spheres, 8 lights, depth 16) at a REDUCED size, 1920x1080 with 2x2
+         samples - config 5 itself (7680x4320, 64 spp) is sized for 8 GPUs
+--config c2 --gpus 8 is the metric's "1080p at 8 GPUs".  --scaling weak grows the frame with N instead (N x the
+pixels of the config's frame at its aspect ratio; per-GPU work fixed).
+
+Rank 0 prints ONE JSON line.  `value` = rays the REFERENCE traces for the frame (primary + shadow +
+reflection + transmission, counted by the kernels and equal to the reference's own counters) of all ranks /
+max-over-ranks time; `config.rays_traced_per_step` leaves out the primary rays of pixel tiles that were shown to
+see nothing and were never generated.  `roofline` prices the dominant kernel (k_primary) with the algorithmic
+FLOP constants of SURVEY.md section 8d against the FP32 vector peak: reference-equivalent work / time, NOT a
+utilisation - `roofline.executed_frac` (vector lane operations really issued / what the SIMDs can issue) is
+that.  `cpu_baseline` times the reference (or the oracle port) on the host.
 """
 import argparse
-import ctypes as C
 import json
 import math
 import os
@@ -26,28 +38,38 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
+import numpy as np  # noqa: E402,F401
 import torch  # noqa: E402
 
 import raytracer_amd as rt  # noqa: E402
-from raytracer_amd.dist import FrameGather, RowPlan  # noqa: E402
+from raytracer_amd.dist import FramePipeline, RowPlan  # noqa: E402
 
 PEAK_FP32_TFLOPS = 157.3  # MI355X vector FP32 peak, MI355X_MICROARCH.md "Chip-level parameters"
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+
+# name -> (scene, W, H, sqrtSpp, depth, default steps, default warmup); scene None = the reference's hard-coded one,
+# else rt_scene_synthetic's arguments (seed, spheres, quads, lights, kind) - SURVEY.md section 8d
+CONFIGS = {
+    "c1": (None, 640, 480, 1, 4, 200, 30),
+    "c2": (None, 1920, 1080, 4, 8, 200, 30),
+    "c3": (None, 3840, 2160, 4, 8, 60, 10),
+    "c4": ((0xC0FFEE04, 1024, 4, 1, 0), 3840, 2160, 4, 8, 6, 2),
+    "c5s": ((0xC0FFEE05, 16384, 0, 8, 1), 1920, 1080, 2, 16, 4, 1),
+}
 
 
-def frame_for(n_gpus):
-    """Frame size with n_gpus x the pixels of 1920x1080 at 16:9; height a multiple of 8*n_gpus."""
+def grown_frame(W, H, n_gpus):
+    """--scaling weak: n_gpus x the pixels of the WxH frame at its aspect ratio; height a multiple of 8*n_gpus."""
     if n_gpus == 1:
-        return 1920, 1080
-    if n_gpus == 4:
-        return 3840, 2160  # BASELINE config 3 (2160 = 4 * 540)
-    h = int(round(1080 * math.sqrt(n_gpus) / (8 * n_gpus))) * 8 * n_gpus
-    w = int(round(h * 16 / 9 / 32)) * 32
+        return W, H
+    h = int(round(H * math.sqrt(n_gpus) / (8 * n_gpus))) * 8 * n_gpus
+    w = int(round(h * W / H / 32)) * 32
     return w, h
 
 
-def algorithmic_flops_k0(st, samples, n_lights, nv=4):
-    """FLOPs the reference would spend on the work k_primary covers."""
+def algorithmic_flops_k0(st, samples, nv=4):
+    """FLOPs the reference would spend on the work k_primary covers, from the
+    instrumented pass's counts of ray-object tests by outcome."""
     sph = 20 * st["k0_sphere_tests"] + 15 * st["k0_sphere_hits"]
     poly_full = 19 + 27 * nv + 1
     poly = (12 * st["k0_polygon_rej_parallel"] + 13 * st["k0_polygon_rej_behind"]
@@ -59,31 +81,14 @@ def algorithmic_flops_k0(st, samples, n_lights, nv=4):
     return sph + poly + gen + nodes + lights + spawn
 
 
-def measured_traffic(W, H, sqrt_spp, depth):
-    """HBM bytes per k_primary launch from the committed PMC passes (profiles/r01_traffic.json:
-    FETCH_SIZE / WRITE_SIZE collected in separate rocprofv3 runs, corrected as the MI355X guide
-    prescribes).  Only for the workload they were collected on; otherwise None."""
+def pmc_for(workload_key, numerics):
+    """Counters of k_primary from the committed rocprofv3 --pmc passes (profiles/r02_pmc.json: separate runs,
+    FETCH_SIZE doubled as the MI355X guide prescribes), only for the workload and build they were collected on."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-    except OSError:
+        t = json.load(open(PMC_FILE))
+    except (OSError, ValueError):
         return None
-    w = t["workload"]
-    if (w["W"], w["H"], w["sqrt_spp"], w["depth"]) != (W, H, sqrt_spp, depth):
-        return None
-    return t["k_primary"]["bytes_per_launch"]
-
-
-def executed_lane_ops(W, H, sqrt_spp, depth):
-    """SURVEY 8(d) asks for "executed" next to "algorithmic": vector lane operations k_primary really issues
-    per launch (SQ_INSTS_VALU x 64 from the committed PMC pass), same workload condition as above."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-    except OSError:
-        return None
-    w = t["workload"]
-    if (w["W"], w["H"], w["sqrt_spp"], w["depth"]) != (W, H, sqrt_spp, depth):
-        return None
-    return t["k_primary"].get("executed_valu_lane_ops_per_launch")
+    return t.get(f"{workload_key}:{numerics}")
 
 
 def cpu_all_cores(O, sc, W, H, sqrt_spp, depth):
@@ -101,18 +106,13 @@ def cpu_all_cores(O, sc, W, H, sqrt_spp, depth):
             "sample": f"2 full {W}x{H} frames, oracle/rt_oracle.c -O2 -fopenmp, {dt:.2f} s"}
 
 
-def cpu_baseline(W, H, sqrt_spp, depth, budget_rows):
-    """Reference (oracle/_ref, when it travelled) or the oracle port on ONE host core, on a row
-    slab of the same frame.  Returns the JSON object."""
+def cpu_baseline(sc, builtin, W, H, sqrt_spp, depth):
+    """The reference (oracle/_ref, when it travelled; whole frames of its own scene only) or the oracle port on
+    ONE host core - the reference is single-threaded - on a bounded sample of the same workload."""
     from oracle import oracle_py as O
-    sc = rt.Scene.builtin()
-    row0 = (H - budget_rows) // 2
-    if O.have_ref():
-        # the untouched reference renders whole frames only: time a frame with H*budget/H rows is not
-        # possible, so render the full frame at reduced supersampling-invariant size instead
-        # whole frames until about 10 s of CPU work are done (bounded: at most 4)
+    if builtin and O.have_ref() and W * H * sqrt_spp * sqrt_spp <= 40e6:
         total, frames, rays = 0.0, 0, 0
-        while total < 10.0 and frames < 4:
+        while total < 10.0 and frames < 4:  # whole frames until about 10 s of CPU work are done
             t0 = time.perf_counter()
             _, cnt = O.ref_raytrace(sc.c, W, H, sqrt_spp, depth)
             total += time.perf_counter() - t0
@@ -122,23 +122,35 @@ def cpu_baseline(W, H, sqrt_spp, depth, budget_rows):
                 "sample": f"{frames} full {W}x{H} frames, sqrtSpp {sqrt_spp}, depth {depth}, gcc -O2 build of the "
                           f"untouched reference, single-threaded like the reference, {total:.2f} s",
                 "all_cores": cpu_all_cores(O, sc, W, H, sqrt_spp, depth)}
+    # big frames / synthetic scenes: row slabs from the middle of the frame, until ~10 s of CPU work are done
     cam = O.prepare_camera(sc.c, W, H, sqrt_spp, depth)
-    t0 = time.perf_counter()
-    _, _, cnt = O.render(sc.c, cam, row0, budget_rows, nthreads=1)
-    dt = time.perf_counter() - t0
-    rays = (cnt["primary_rays"] + cnt["shadow_rays"] + cnt["reflection_rays"] + cnt["transmission_rays"])
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
-            "sample": f"rows [{row0},{row0 + budget_rows}) of the {W}x{H} frame, sqrtSpp {sqrt_spp}, "
-                      f"depth {depth}, oracle/rt_oracle.c -O2, {dt:.2f} s"}
+    rows, total, rays, used = 1, 0.0, 0, 0
+    row0 = H // 2
+    while total < 10.0 and row0 + rows <= H and used < 64:
+        t0 = time.perf_counter()
+        _, _, cnt = O.render(sc.c, cam, row0, rows, nthreads=1)
+        total += time.perf_counter() - t0
+        rays += cnt["primary_rays"] + cnt["shadow_rays"] + cnt["reflection_rays"] + cnt["transmission_rays"]
+        row0 += rows
+        used += rows
+        rows = min(rows * 2, 16)
+    return {"value": rays / total / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+            "sample": f"{used} rows from the middle of the {W}x{H} frame, sqrtSpp {sqrt_spp}, depth {depth}, "
+                      f"oracle/rt_oracle.c -O2, {total:.2f} s"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=30)  # the clocks settle over the first ~20 frames
-    ap.add_argument("--sqrt-spp", type=int, default=4)
-    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)  # the clocks settle over the first ~20 frames
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
+                    help="workload (module docstring); default c2 on one GPU, c3 on several")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong (default) = the config's frame, fixed, split over the ranks; weak = the frame "
+                         "grows to N x the pixels")
+    ap.add_argument("--sqrt-spp", type=int, default=None)
+    ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--inflight", type=int, default=2,
                     help="frames submitted ahead (each with its own render context); they share ONE HIP stream, "
                          "so kernels of different frames never overlap - only the host's submit/collect latency "
@@ -155,9 +167,10 @@ def main():
                          "for their gathers: step = render + collective)")
     ap.add_argument("--numerics", choices=["fast", "exact"], default="fast",
                     help="fast (default): the tolerance build of the trace kernels (FMA, 1-ulp rcp / rsq / sqrt; pixels "
-                         "within the north star's +-1 LSB / 1e-4); exact: every operation rounded like the reference's "
-                         "x86 build (pixels bit-identical to the reference's)")
+                         "within the north star's +-1 LSB / 1e-4 on the reference's scene); exact: every operation "
+                         "rounded like the reference's x86 build (pixels bit-identical to the reference's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-generic", action="store_true", help="skip the short extra run with the generic kernels")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -180,99 +193,88 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    W, H = frame_for(world)
-    sqrt_spp, depth = args.sqrt_spp, args.depth
-    scene = rt.Scene.builtin()
+    cfg = args.config or ("c2" if world == 1 else "c3")
+    scene_args, W, H, sqrt_spp, depth, def_steps, def_warm = CONFIGS[cfg]
+    sqrt_spp = args.sqrt_spp or sqrt_spp
+    depth = depth if args.depth is None else args.depth
+    steps = def_steps if args.steps is None else args.steps
+    warmup = def_warm if args.warmup is None else args.warmup
+    scaling = "weak" if world == 1 else args.scaling  # (one GPU: the per-GPU work is the config's, either way)
+    if world > 1 and args.scaling == "weak":
+        W, H = grown_frame(W, H, world)
+    builtin = scene_args is None
+    scene = rt.Scene.builtin() if builtin else rt.Scene.synthetic(*scene_args)
     cam = rt.prepare_camera(scene, W, H, sqrt_spp, depth)
     plan = RowPlan(H, world)
+    numerics = rt.NUMERICS_FAST if args.numerics == "fast" else rt.NUMERICS_EXACT
 
     # `inflight` frames are submitted ahead: each has its own render context (ray queues, node pool,
     # counters) and frame buffers.  By default they share one HIP stream: the GPU runs the frames back
     # to back while the host collects frame k's counters and submits frame k+2.
     inflight = max(1, args.inflight)
-    ctxs, streams, gathers = [], [], []
-    shared = torch.cuda.Stream(device=dev)
     tail = torch.cuda.Stream(device=dev) if args.tail_stream == "on" and not args.overlap else None
+    ctxs = []
     for _ in range(inflight):
-        c = rt.Context(device=local_rank)
+        c = rt.Context(device=local_rank)  # queue capacity sized by the first render of this rank's share
         c.upload(scene)
-        c.set_numerics(rt.NUMERICS_FAST if args.numerics == "fast" else rt.NUMERICS_EXACT)
+        c.set_numerics(numerics)
         if tail is not None:
             c.set_tail_stream(tail.cuda_stream)
         ctxs.append(c)
-        streams.append(torch.cuda.Stream(device=dev) if args.overlap else shared)
-        gathers.append(FrameGather(plan, W, torch.int32, dev, rank=rank))  # 0xFFRRGGBB bit patterns
 
-    # N > 1: the in-place all-gather of frame k and its de-interleave copy (the library's streaming
-    # kernel) run on a second stream behind an event, overlapping the render of frame k+1
-    # (--gather-stream same keeps them on the render stream).
-    comm = (torch.cuda.Stream(device=dev) if args.gather_stream == "side" else shared) if world > 1 else None
-    rendered = [torch.cuda.Event() for _ in range(inflight)]
-    gathered = [torch.cuda.Event() for _ in range(inflight)]
+    def render(i, k, target, stream):
+        if world == 1:
+            ctxs[k].render_rows(cam, target.data_ptr(), 0, 0, H, stream.cuda_stream)
+        else:
+            ctxs[k].render_interleaved(cam, target.data_ptr(), 0, rank, world, stream.cuda_stream)
 
-    def submit(i):
-        k = i % inflight
-        st, fg, ctx = streams[k], gathers[k], ctxs[k]
-        with torch.cuda.stream(st):
-            if world == 1:
-                ctx.render_rows(cam, fg.frame.data_ptr(), 0, 0, H, st.cuda_stream)
-                return
-            if i >= inflight:
-                st.wait_event(gathered[k])  # the previous gather out of this frame's buffers is done
-            ctx.render_interleaved(cam, fg.local.data_ptr(), 0, rank, world, st.cuda_stream)
-            rendered[k].record(tail if tail is not None else st)  # (the frame is complete on the tail stream)
-        with torch.cuda.stream(comm):
-            comm.wait_event(rendered[k])
-            fg.gather(collective=not fake)  # in-place RCCL all-gather of the local slices + de-interleave
-            gathered[k].record(comm)
+    def finish(i, k):
+        return ctxs[k].finish()  # waits for the render, checks the queues, reads the counters
 
-    def collect(i):
-        k = i % inflight
-        st = ctxs[k].finish()  # waits for the render, checks the queues, reads the counters
-        return st
+    pipe = FramePipeline(plan, W, torch.int32, dev, rank, render, finish, inflight=inflight,  # 0xFFRRGGBB bit patterns
+                         gather_stream=args.gather_stream, done_stream=tail, collective=not fake,
+                         render_streams=[torch.cuda.Stream(device=dev) for _ in range(inflight)] if args.overlap else None)
 
-    # instrumented pass (outside the timed region): algorithmic work of this rank's share
-    tmp = torch.zeros((plan.local_rows, W), dtype=torch.int32, device=dev)
+    # instrumented pass (outside the timed region, exact kernels): algorithmic work of this rank's share
+    full = torch.zeros((H, W), dtype=torch.int32, device=dev)
     if world == 1:
-        st_alg = ctxs[0].render_stats(cam, gathers[0].frame.data_ptr(), 0, 0, H, 0).as_dict()
+        st_alg = ctxs[0].render_stats(cam, full.data_ptr(), 0, 0, H, 0).as_dict()
     else:
         # the instrumented kernels render contiguous rows: add up this rank's own 8-row blocks (a slab
         # would not do - the top slab is all sky while the timed cyclic blocks are a fair sample)
-        full = torch.zeros((H, W), dtype=torch.int32, device=dev)
         st_alg = {}
         for y, n, _ in plan.rows_of(rank):
             d = ctxs[0].render_stats(cam, full.data_ptr(), 0, y, n, 0).as_dict()
-            for k, v in d.items():
+            for key, v in d.items():
                 if isinstance(v, (int, float)):
-                    st_alg[k] = st_alg.get(k, 0) + v
-        del full
-    del tmp
+                    st_alg[key] = st_alg.get(key, 0) + v
+    del full
     my_rows = sum(n for _, n, _ in plan.rows_of(rank)) if world > 1 else H
 
-    for i in range(args.warmup):
-        submit(i)
-        collect(i)
+    for i in range(warmup):
+        pipe.submit(i)
+        pipe.collect(i)
     for c in ctxs:
         c.set_timing(True)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    k0_ms, k0_n, rays_rank, shadow_rank = 0.0, 0, 0, 0
-    for i in range(args.steps):
+    acc = {"k0_ms": 0.0, "k0_n": 0, "rays": 0, "shadow": 0, "culled": 0}
+
+    def tally(st):
+        acc["k0_ms"] += st.k0_ms
+        acc["k0_n"] += st.k0_launches
+        acc["rays"] += st.primary_rays + st.shadow_rays + st.reflection_rays + st.transmission_rays
+        acc["shadow"] += st.shadow_rays
+        acc["culled"] += st.primary_rays_culled
+
+    for i in range(steps):
         if i >= inflight:
-            st = collect(i - inflight)
-            k0_ms += st.k0_ms
-            k0_n += st.k0_launches
-            rays_rank += (st.primary_rays + st.shadow_rays + st.reflection_rays + st.transmission_rays)
-            shadow_rank += st.shadow_rays
-        submit(i)
-    for i in range(max(0, args.steps - inflight), args.steps):
-        st = collect(i)
-        k0_ms += st.k0_ms
-        k0_n += st.k0_launches
-        rays_rank += (st.primary_rays + st.shadow_rays + st.reflection_rays + st.transmission_rays)
-        shadow_rank += st.shadow_rays
+            tally(pipe.collect(i - inflight))
+        pipe.submit(i)
+    for i in range(max(0, steps - inflight), steps):
+        tally(pipe.collect(i))
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -280,60 +282,110 @@ def main():
     for c in ctxs:
         c.set_timing(False)
 
-    tot = torch.tensor([dt, float(rays_rank), float(shadow_rank)], dtype=torch.float64, device=dev)
+    tot = torch.tensor([dt, float(acc["rays"]), float(acc["shadow"]), float(acc["culled"])], dtype=torch.float64, device=dev)
     if dist is not None:
         tmax = tot.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dt_max, rays_all, shadow_all = float(tmax[0]), float(tot[1]), float(tot[2])
+        dt_max = float(tmax[0])
     else:
-        dt_max, rays_all, shadow_all = dt, float(rays_rank), float(shadow_rank)
+        dt_max = dt
+    rays_all, shadow_all, culled_all = float(tot[1]), float(tot[2]), float(tot[3])
 
     if rank == 0 or fake:  # (a rehearsal prints whichever rank it plays)
         samples = W * my_rows * sqrt_spp * sqrt_spp
-        flops_k0 = algorithmic_flops_k0(st_alg, samples, scene.c.nLights)
-        k0_avg_ms = k0_ms / max(k0_n, 1)
-        launches_per_step = k0_n / max(args.steps, 1)
-        achieved = flops_k0 / max(launches_per_step, 1) / (k0_avg_ms * 1e-3) / 1e12 if k0_avg_ms > 0 else 0.0
+        flops_k0 = algorithmic_flops_k0(st_alg, samples)
+        k0_avg_ms = acc["k0_ms"] / max(acc["k0_n"], 1)
+        launches_per_step = max(acc["k0_n"] / max(steps, 1), 1)
+        achieved = flops_k0 / launches_per_step / (k0_avg_ms * 1e-3) / 1e12 if k0_avg_ms > 0 else 0.0
+        scene_name = ("builtin Whitted scene" if builtin else
+                      f"synthetic scene (seed {scene_args[0]:#x}: {scene_args[1]} spheres, {scene_args[2]} quads, "
+                      f"{scene_args[3]} lights)")
+        split = "" if world == 1 else (f", cyclic 8-row blocks over {world} GPUs + RCCL all-gather"
+                                       + (", the frame fixed" if scaling == "strong" else ", the frame grown with N"))
+        grid_scene = (not builtin) and scene_args[1] > 128
         out = {
             "metric": "Mrays/s (primary+secondary) Whitted 1080p 16spp at 1/8 GPUs; % FP32 VALU peak",
             "value": rays_all / dt_max / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt_max / args.steps * 1e3,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": dt_max / steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (the reference's hard-coded Whitted scene, scene.c:86-258)"
+            "data": ("synthetic (the reference's hard-coded Whitted scene, scene.c:86-258)" if builtin else
+                     "synthetic (seeded random scene, rt_scene_synthetic)")
                     + (f"; REHEARSAL of rank {rank} of {world} on one GPU, no collective" if fake else ""),
-            "config": {"workload": f"builtin Whitted scene {W}x{H}, sqrtSpp {sqrt_spp} ({sqrt_spp * sqrt_spp} spp), "
-                                   f"depth {depth}" + ("" if world == 1 else f", cyclic 8-row blocks over {world} GPUs + RCCL all-gather"),
-                       "rays_per_step": rays_all / args.steps,
+            "config": {"workload": f"{cfg}: {scene_name} {W}x{H}, sqrtSpp {sqrt_spp} ({sqrt_spp * sqrt_spp} spp), "
+                                   f"depth {depth}{split}",
+                       "rays_per_step": rays_all / steps,
                        # the sub-total without shadow rays, and its rate
-                       "rays_per_step_without_shadow": (rays_all - shadow_all) / args.steps,
+                       "rays_per_step_without_shadow": (rays_all - shadow_all) / steps,
                        "mrays_per_s_without_shadow": (rays_all - shadow_all) / dt_max / 1e6,
+                       # rays really generated and traced: the primary rays of tiles shown to see nothing are not
+                       "rays_traced_per_step": (rays_all - culled_all) / steps,
+                       "mrays_traced_per_s": (rays_all - culled_all) / dt_max / 1e6,
                        "numerics": args.numerics,
-                       "frames_in_flight": inflight, "streams": "one per frame" if args.overlap else ("shared + tail stream" if tail is not None else "shared"),
+                       "frames_in_flight": inflight,
+                       "streams": "one per frame" if args.overlap else ("shared + tail stream" if tail is not None else "shared"),
                        "parallelism": "1 GPU" if world == 1 else f"cyclic 8-row blocks over {world} GPUs"},
             "roofline": {"bound": "fp32_valu", "kernel": "k_primary", "achieved": achieved,
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
-                         "traffic": measured_traffic(W, H, sqrt_spp, depth) if world == 1 else None,
-                         "traffic_unit": "bytes per launch (PMC, profiles/r01_traffic.json)",
-                         "algorithmic_flop_per_launch": flops_k0 / max(launches_per_step, 1),
-                         "executed_valu_lane_ops_per_launch": executed_lane_ops(W, H, sqrt_spp, depth) if world == 1 else None,
+                         "definition": "reference-equivalent FLOPs of the work k_primary covers (SURVEY 8d constants x the "
+                                       "instrumented pass's test counts" + (", i.e. the tests the sphere grid makes, not the "
+                                       "reference's loop over every sphere" if grid_scene else "") + ") / launch time: the "
+                                       "kernel skips tiles that see nothing and decides most polygon tests by a cheap screen, "
+                                       "so this is not a utilisation - executed_frac is",
+                         "traffic": None, "algorithmic_flop_per_launch": flops_k0 / launches_per_step,
                          "avg_launch_ms": k0_avg_ms},
         }
-        # the secondary bound, HBM, from the measured bytes of the same kernel
-        tr = out["roofline"]["traffic"]
-        if tr and k0_avg_ms > 0:
-            gbs = tr / (k0_avg_ms * 1e-3) / 1e9
-            out["roofline"]["secondary"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s",
-                                            "frac": gbs / 8000.0}
+        pmc = pmc_for(cfg, args.numerics) if world == 1 and (W, H, sqrt_spp, depth) == CONFIGS[cfg][1:5] else None
+        if pmc:
+            r = out["roofline"]
+            r["traffic"] = pmc.get("hbm_bytes_per_launch")
+            r["traffic_unit"] = "bytes per launch (PMC, profiles/r02_pmc.json)"
+            lane_ops = pmc.get("valu_lane_ops_per_launch")
+            if lane_ops and k0_avg_ms > 0:
+                # what the SIMDs can issue: one vector instruction (64 lanes) per 2 cycles per SIMD = peak / 2 lane-ops/s
+                r["executed_valu_lane_ops_per_launch"] = lane_ops
+                r["executed_frac"] = lane_ops / (k0_avg_ms * 1e-3) / (PEAK_FP32_TFLOPS * 1e12 / 2)
+            for key in ("valu_busy", "lds_conflict_rate", "waves_per_simd"):
+                if key in pmc:
+                    r[key] = pmc[key]
+            if r["traffic"] and k0_avg_ms > 0:  # the secondary bound, HBM
+                gbs = r["traffic"] / (k0_avg_ms * 1e-3) / 1e9
+                r["secondary"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0}
+        if world == 1 and builtin and not args.no_generic:
+            # the same frames with the kernels any OTHER scene gets (nothing compiled for this scene's counts)
+            g = ctxs[0]
+            g.set_specialization(False)
+            g.set_timing(True)
+            frame = pipe.gathers[0].frame
+            ms, n, tg = 0.0, 0, 0.0
+            for i in range(10 + 30):
+                if i == 10:
+                    torch.cuda.synchronize()
+                    tg = time.perf_counter()
+                g.render_rows(cam, frame.data_ptr(), 0, 0, H, pipe.streams[0].cuda_stream)
+                st = g.finish()
+                if i >= 10:
+                    ms += st.k0_ms
+                    n += st.k0_launches
+            torch.cuda.synchronize()
+            tg = (time.perf_counter() - tg) / 30
+            g.set_specialization(True)
+            g.set_timing(False)
+            gms = ms / max(n, 1)
+            out["generic_kernels"] = {"k_primary_ms": gms,
+                                      "frac": flops_k0 / (gms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS if gms else 0.0,
+                                      "ms_per_step_one_frame_at_a_time": tg * 1e3,
+                                      "note": "30 frames, one at a time, with the kernels every scene shape other than the "
+                                              "reference's gets (rt_hip_ctx_set_specialization(ctx, 0))"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(W, H, sqrt_spp, depth, budget_rows=H)
+            out["cpu_baseline"] = cpu_baseline(scene, builtin, W, H, sqrt_spp, depth)
         print(json.dumps(out), flush=True)
     for c in ctxs:
         c.close()

@@ -148,6 +148,11 @@ typedef struct {
      * summed over batches; 0 unless timing was enabled with rt_hip_ctx_set_timing.        */
     float    k0_ms;
     uint32_t k0_launches;
+    /* primary rays of pixel tiles that were finished WITHOUT tracing: every sample of such a tile was
+     * shown to miss every object (the reference traces them and gets the background, raytrace.c:700-703).
+     * They are part of primary_rays (the reference's count); primary_rays - primary_rays_culled were
+     * generated and traced.  0 for instrumented renders, which trace everything. */
+    uint64_t primary_rays_culled;
 } rt_hip_stats;
 
 /* ------------------------------------------------------------------------------------ */
@@ -195,7 +200,10 @@ typedef struct rt_hip_ctx rt_hip_ctx;
 #define RT_E_NOSCENE   (-10003)   /* render before rt_hip_scene_upload              */
 
 /* Create a render context on HIP device `device` (-1 = current).  max_queue_rays = capacity
- * of each per-level ray queue and of the node pool (0 = RT_HIP_QUEUE_CAP from the environment, else 64 Mi entries). */
+ * of each per-level ray queue and of the node pool, 152 bytes per entry.  0 = sized by the renders: the
+ * first render allocates one entry per primary sample of its job (at least 1 Mi, at most
+ * RT_HIP_QUEUE_CAP from the environment, else 64 Mi entries = 9.5 GiB), a later, larger job re-allocates;
+ * jobs beyond the capacity are rendered in row batches. */
 int  rt_hip_ctx_create(rt_hip_ctx **out, int device, uint64_t max_queue_rays);
 void rt_hip_ctx_destroy(rt_hip_ctx *ctx);
 
@@ -306,6 +314,12 @@ int  rt_hip_ctx_set_numerics(rt_hip_ctx *ctx, int mode);
  * work that reads the pixels behind it, or call rt_hip_finish.  No counterpart in the reference (its
  * frames are strictly sequential, main.c:159-165).  Pixels and counters are unchanged. */
 int  rt_hip_ctx_set_tail_stream(rt_hip_ctx *ctx, void *stream);
+
+/* Kernels compiled for the scene shape the reference's parse_scene always returns (2 spheres, 1 quad, 1
+ * light: every count a compile-time constant) are used when the uploaded scene has that shape; enable = 0
+ * makes the context use the generic kernels for every scene (same pixels; what any other scene gets).
+ * No counterpart in the reference. */
+void rt_hip_ctx_set_specialization(rt_hip_ctx *ctx, int enable);
 
 /* Bracket the fused primary kernel with HIP events on the render stream (k0_ms). */
 void rt_hip_ctx_set_timing(rt_hip_ctx *ctx, int enable);

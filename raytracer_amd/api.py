@@ -173,6 +173,10 @@ class Context:
         fused multiply-adds, 1-ulp rcp / rsq / sqrt) - rt_hip_ctx_set_numerics"""
         check(load().rt_hip_ctx_set_numerics(self._h, int(mode)), "rt_hip_ctx_set_numerics")
 
+    def set_specialization(self, on):
+        """False: generic kernels also for the reference's scene shape (rt_hip_ctx_set_specialization)"""
+        load().rt_hip_ctx_set_specialization(self._h, int(bool(on)))
+
     def set_tail_stream(self, stream):
         """hipStream_t (int) for the latency-bound tail of every batch, 0 = none (rt_hip_ctx_set_tail_stream)"""
         check(load().rt_hip_ctx_set_tail_stream(self._h, stream or None), "rt_hip_ctx_set_tail_stream")

@@ -92,8 +92,11 @@ struct rt_hip_ctx {
     std::vector<Batch> todo;         /* batches still to enqueue                      */
     /* options */
     bool timing = false;
+    bool no_shape = false; /* generic kernels only (survives scene uploads) */
     int shading = RT_SHADE_PHONG;
     int numerics = RT_NUMERICS_EXACT;
+    bool auto_cap = false;  /* capacity follows the jobs (rt_hip_ctx_create with 0 entries) */
+    uint64_t cap_limit = 0; /* ... up to this many entries */
     /* optional second stream for the latency-bound tail of a batch (rt_hip_ctx_set_tail_stream) */
     hipStream_t tail_stream = nullptr;
     hipEvent_t head_done = nullptr, tail_done = nullptr;
@@ -390,6 +393,7 @@ void accumulate(rt_hip_stats &s, const uint32_t *cnt, uint32_t levels)
     s.k0_lights_lit += st[ST_K0_LIT];
     s.k0_nodes_sphere += st[ST_K0_NODES_SPH];
     s.k0_nodes_polygon += st[ST_K0_NODES_POLY];
+    s.primary_rays_culled += st[ST_K0_CULLED];
 }
 
 /* Enqueue up to kMaxBatches batches of the work list (one counter slot each) and the copy of
@@ -523,6 +527,43 @@ uint64_t default_batch_samples(const rt_hip_ctx *c)
     return m ? m : 1;
 }
 
+uint64_t round_cap(uint64_t cap)
+{
+    if (cap < 1024)
+        cap = 1024;
+    if (cap > (1ull << 28))
+        cap = 1ull << 28; /* node links are 29-bit, ray parents 31-bit */
+    return (cap + RT_SHARDS - 1) / RT_SHARDS * RT_SHARDS; /* whole shards */
+}
+
+/* (re)allocate the queues and the node pool for `cap` entries: one blob of 6 queue arrays + 3 node arrays of
+ * cap float4 each + one of cap float2.  Nothing of this context may be in flight. */
+int ensure_work(rt_hip_ctx *c, uint64_t cap)
+{
+    if (c->work_blob && c->cap == cap)
+        return 0;
+    if (c->work_blob) {
+        HIP_TRY(hipFree(c->work_blob)); /* (waits for the device) */
+        c->work_blob = nullptr;
+        c->cap = 0;
+    }
+    const size_t arr = align_up(cap * sizeof(float4), 256);
+    const hipError_t e = hipMalloc(&c->work_blob, arr * 9 + arr / 2);
+    if (e != hipSuccess) {
+        c->work_blob = nullptr;
+        set_err("allocating %zu bytes of queue memory (%llu entries) on device %d failed: %s", arr * 9 + arr / 2,
+                (unsigned long long)cap, c->device, hipGetErrorString(e));
+        return -(int)e;
+    }
+    c->cap = cap;
+    c->W.base = (char *)c->work_blob; /* slots 0..9, the last one (float2) half as long: rt_device.h */
+    c->W.stride = arr;
+    c->W.cap = (uint32_t)cap;
+    c->W.capS = (uint32_t)(cap / RT_SHARDS);
+    c->seen_valid = false;
+    return 0;
+}
+
 void drop_events(rt_hip_ctx *c)
 {
     for (hipEvent_t e : c->ev)
@@ -593,18 +634,15 @@ int rt_hip_ctx_create(rt_hip_ctx **out, int device, uint64_t max_queue_rays)
     rt_hip_ctx *c = new rt_hip_ctx();
     c->device = device;
     uint64_t cap = max_queue_rays;
-    if (!cap) {
+    if (!cap) { /* sized by the renders (submit): nothing is allocated for the queues yet */
         const char *env = getenv("RT_HIP_QUEUE_CAP");
         cap = env ? strtoull(env, nullptr, 0) : 0;
-        if (!cap)
-            cap = kDefaultCap;
+        c->auto_cap = true;
+        c->cap_limit = round_cap(cap ? cap : kDefaultCap);
+        cap = 0;
+    } else {
+        cap = round_cap(cap);
     }
-    if (cap < 1024)
-        cap = 1024;
-    if (cap > (1ull << 28))
-        cap = 1ull << 28; /* node links are 29-bit, ray parents 31-bit */
-    cap = (cap + RT_SHARDS - 1) / RT_SHARDS * RT_SHARDS; /* whole shards */
-    c->cap = cap;
     int rc = ctx_set_device(c);
     if (!rc) /* the library's per-device set-up: the address of rt_hip_tone_static's scratch array */
         rc = rt_tone_static_init();
@@ -612,9 +650,11 @@ int rt_hip_ctx_create(rt_hip_ctx **out, int device, uint64_t max_queue_rays)
         delete c;
         return rc;
     }
-    /* one blob: 6 queue arrays + 3 node arrays of cap float4 each + one of cap float2 */
-    const size_t arr = align_up(cap * sizeof(float4), 256);
-    hipError_t e = hipMalloc(&c->work_blob, arr * 9 + arr / 2);
+    hipError_t e = hipSuccess;
+    if (cap && (rc = ensure_work(c, cap))) {
+        rt_hip_ctx_destroy(c);
+        return rc;
+    }
     if (e == hipSuccess)
         e = hipMalloc((void **)&c->d_counters, (size_t)kMaxBatches * RT_COUNTER_WORDS * sizeof(uint32_t));
     if (e == hipSuccess)
@@ -625,15 +665,10 @@ int rt_hip_ctx_create(rt_hip_ctx **out, int device, uint64_t max_queue_rays)
     if (e == hipSuccess)
         e = hipMemset(c->d_counters, 0, (size_t)kMaxBatches * RT_COUNTER_WORDS * sizeof(uint32_t));
     if (e != hipSuccess) {
-        set_err("allocating %zu bytes of queue memory failed: %s", arr * 9 + arr / 2, hipGetErrorString(e));
+        set_err("allocating the counter blocks failed: %s", hipGetErrorString(e));
         rt_hip_ctx_destroy(c);
         return -(int)e;
     }
-    char *p = (char *)c->work_blob;
-    c->W.base = p; /* slots 0..9, the last one (float2) half as long: rt_device.h */
-    c->W.stride = arr;
-    c->W.cap = (uint32_t)cap;
-    c->W.capS = (uint32_t)(cap / RT_SHARDS);
     *out = c;
     return 0;
 }
@@ -659,6 +694,14 @@ void rt_hip_ctx_destroy(rt_hip_ctx *c)
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     delete c;
+}
+
+void rt_hip_ctx_set_specialization(rt_hip_ctx *c, int enable)
+{
+    if (c) {
+        c->S.noShape = enable ? 0u : 1u;
+        c->no_shape = !enable;
+    }
 }
 
 void rt_hip_ctx_set_timing(rt_hip_ctx *c, int enable)
@@ -1067,6 +1110,7 @@ int rt_hip_scene_upload(rt_hip_ctx *c, const rt_scene *sc)
     S.nLights = nL;
     S.tabSlots = (uint32_t)tab.size();
     S.tabInLds = 0;
+    S.noShape = c->no_shape ? 1u : 0u;
     S.tabInLds = (nSph <= RT_TILE_SPHERES &&
                   rt_scene_lds_bytes(S) - RT_PARK_FLOATS * sizeof(float) +
                           (tab.size() + nSph + nPoly) * sizeof(float4) /* tables + k_primary's eye terms */ <=
@@ -1133,6 +1177,14 @@ static int submit(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb, float *
     c->todo.clear();
     drop_events(c);
     memset(&c->stats, 0, sizeof c->stats);
+    if (c->auto_cap) {
+        /* one entry per primary sample of the job (the batch plan's rule), within [1 Mi, the limit]; the
+         * blob only ever grows */
+        uint64_t want = (uint64_t)job.ntiles * 8u * c->C.W * c->C.sqrtSpp * c->C.sqrtSpp;
+        want = round_cap(want < (1ull << 20) ? (1ull << 20) : want > c->cap_limit ? c->cap_limit : want);
+        if (want > c->cap && (rc = ensure_work(c, want)))
+            return rc;
+    }
     c->pending = true;
     if (job.ntiles == 0)
         return 0;

@@ -55,6 +55,7 @@ struct DevScene {
     uint32_t nSph, nPoly, nPolySlots, nObj, nLights;
     uint32_t tabSlots;        /* 2*nLights + 5*nObj                                          */
     uint32_t tabInLds;        /* the tables are small enough to be staged in LDS per block   */
+    uint32_t noShape;         /* use the generic kernels whatever the scene's shape (rt_hip_ctx_set_specialization) */
     float bg[3];
     float ambient[3];
 };
@@ -181,6 +182,7 @@ enum {
     ST_K0_SPH_TESTS, ST_K0_SPH_HITS, ST_K0_POLY_TESTS, ST_K0_POLY_PAR, ST_K0_POLY_BEHIND,
     ST_K0_POLY_FULL, ST_K0_LIT, ST_K0_NODES_SPH, ST_K0_NODES_POLY,
     ST_POLY_SCREEN_MISMATCH, ST_POLY_SCREEN_UNSURE,
+    ST_K0_CULLED, /* primary rays of tiles finished without tracing */
     ST_COUNT
 };
 static_assert(2 * ST_COUNT <= CNT_STATS_STRIDE, "statistics do not fit their line");

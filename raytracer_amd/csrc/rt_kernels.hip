@@ -1709,6 +1709,8 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
             }
             if (valid)
                 Wk.pixAcc[pix] = make_float4(accr, accg, accb, __uint_as_float(0u));
+            wave_add_total((uint64_t *)(Wk.counters + CNT_STATS + shard * CNT_STATS_STRIDE), ST_K0_CULLED,
+                           (uint32_t)__popcll(__ballot(valid)) * C.sqrtSpp * C.sqrtSpp);
             return;
         }
     }
@@ -2151,7 +2153,7 @@ using namespace RT_NSNAME;
 int rt_scene_shape(const DevScene &S)
 {
     static const bool off = getenv("RT_HIP_NO_SHAPES") != nullptr; /* development: generic kernels only */
-    if (off)
+    if (off || S.noShape)
         return 0;
     if (S.nSph == 2u && S.nPoly == 1u && S.nPolySlots == 10u && S.nObj == 3u && S.nLights == 1u &&
         S.tabSlots == 17u && S.tabInLds)

@@ -90,6 +90,100 @@ class FrameGather:
         return deinterleave(self.gathered, self.plan, out=self.frame)
 
 
+class _NoStream:
+    """Stand-in for a HIP stream / event on a device without streams (the CPU tests): everything runs in
+    program order, so waiting and recording are nothing."""
+    cuda_stream = 0
+
+    def wait_event(self, ev):
+        pass
+
+    def record(self, stream=None):
+        pass
+
+    def synchronize(self):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class FramePipeline:
+    """`inflight` frames of one rank submitted ahead of their collection: what bench.py times and what
+    tests/test_dist_cpu.py drives with gloo on the CPU - one implementation for both.
+
+    Frame i uses slot k = i % inflight: a FrameGather (its `local` slice is the render target and, in
+    place, this rank's contribution to the all-gather) and the events that order the two streams:
+      render stream:  [wait gathered[k] of the frame that used the slot before]  render(i, k, local, stream)
+      done stream:    where the frame is complete (the render stream, or the tail stream of a context)
+      comm stream:    wait rendered[k]; all-gather in place; de-interleave into frame; record gathered[k]
+    With gather_stream == "same" the comm stream IS the render stream (frames wait for their gathers).
+
+    render(i, k, local, stream): enqueue the render of frame i into `local` ([local_rows, width, ...]) on
+    `stream` (asynchronous).  finish(i, k): wait for the render, return its statistics (an object with
+    overflow_retries, or None).  The gather is enqueued at submit time, behind the render on the device
+    but BEFORE the host has checked the render for queue overflow: a batch that overflowed is rendered
+    again by finish(), after the gather has copied its rows.  collect() therefore refuses such a frame
+    (size the context so that it cannot happen, or gather after collect)."""
+
+    def __init__(self, plan, width, dtype, device, rank, render, finish, inflight=2, gather_stream="side",
+                 done_stream=None, collective=True, group=None, render_streams=None, trailing=()):
+        self.plan, self.rank, self.inflight = plan, rank, max(1, inflight)
+        self.render_fn, self.finish_fn = render, finish
+        self.collective, self.group = collective, group
+        self.cuda = torch.device(device).type == "cuda"
+        self.gathers = [FrameGather(plan, width, dtype, device, trailing=trailing, rank=rank) for _ in range(self.inflight)]
+        if self.cuda:
+            shared = torch.cuda.Stream(device=device)
+            self.streams = list(render_streams) if render_streams else [shared] * self.inflight
+            self.comm = (torch.cuda.Stream(device=device) if gather_stream == "side" else None) if plan.world > 1 else None
+            self.rendered = [torch.cuda.Event() for _ in range(self.inflight)]
+            self.gathered = [torch.cuda.Event() for _ in range(self.inflight)]
+        else:
+            self.streams = [_NoStream()] * self.inflight
+            self.comm = _NoStream() if plan.world > 1 and gather_stream == "side" else None
+            self.rendered = [_NoStream() for _ in range(self.inflight)]
+            self.gathered = [_NoStream() for _ in range(self.inflight)]
+        self.done_stream = done_stream  # where a frame is complete when it is not its render stream
+
+    def _on(self, stream):
+        return torch.cuda.stream(stream) if self.cuda else stream
+
+    def submit(self, i):
+        k = i % self.inflight
+        st, fg = self.streams[k], self.gathers[k]
+        with self._on(st):
+            if self.plan.world == 1:
+                self.render_fn(i, k, fg.frame, st)  # one rank: straight into the frame, nothing to gather
+                return
+            if i >= self.inflight:
+                st.wait_event(self.gathered[k])  # the previous gather out of this slot's buffers is done
+            self.render_fn(i, k, fg.local, st)
+            self.rendered[k].record(self.done_stream if self.done_stream is not None else st)
+        comm = self.comm if self.comm is not None else st
+        with self._on(comm):
+            comm.wait_event(self.rendered[k])
+            fg.gather(group=self.group, collective=self.collective)  # in-place all-gather + de-interleave
+            self.gathered[k].record(comm)
+
+    def collect(self, i):
+        k = i % self.inflight
+        stats = self.finish_fn(i, k)
+        if self.plan.world > 1 and stats is not None and getattr(stats, "overflow_retries", 0):
+            raise RuntimeError("a batch of frame %d overflowed its queues and was rendered again after its rows had "
+                               "been gathered: raise the context's capacity" % i)
+        return stats
+
+    def frame(self, i):
+        """the complete frame i (after collect(i)): waits for its gather"""
+        k = i % self.inflight
+        self.gathered[k].synchronize()
+        return self.gathers[k].frame
+
+
 def tone_slices(local_radiance, local_argb, local_pixels, total_pixels, op, ld_max, l_max, key_pixel_local=-1,
                 use_key=False, group=None):
     """The tone-reproduction step (apply_tone, raytrace.c:792-871) on a frame whose pixels are spread

@@ -30,6 +30,9 @@ def test_single_gpu_line_has_the_contract_fields(tail):
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in d, k
     assert (d["n_gpus"], d["steps"], d["warmup"], d["unit"], d["scaling"], d["dtype"]) == (1, 6, 2, "Mrays/s", "weak", "f32")
+    assert d["config"]["workload"].startswith("c2:") and d["config"]["numerics"] == "exact"
+    assert 0 < d["config"]["rays_traced_per_step"] < d["config"]["rays_per_step"]   # sky tiles are never generated
+    assert d["generic_kernels"]["k_primary_ms"] > d["roofline"]["avg_launch_ms"] * 0.9
     assert d["vs_baseline"] is None and d["higher_is_better"] is True
     assert "workload" in d["config"] and "1920x1080" in d["config"]["workload"]
     assert d["config"]["rays_per_step"] == 57693197          # config 2's ray count, equal to the reference's
@@ -46,3 +49,20 @@ def test_rank_of_a_two_gpu_run_rehearsed_on_one_gpu(gather, tail):
                   {"RT_BENCH_REHEARSE_WORLD": "2", "RT_BENCH_REHEARSE_RANK": "1"})
     assert d["n_gpus"] == 2 and "REHEARSAL" in d["data"]
     assert d["value"] > 1e4
+    # N > 1 renders BASELINE config 3 by default: the 3840x2160 frame, fixed, split over the ranks
+    assert d["scaling"] == "strong" and d["config"]["workload"].startswith("c3:") and "3840x2160" in d["config"]["workload"]
+    assert d["config"]["numerics"] == "fast"
+
+
+def test_other_workloads_and_weak_scaling_are_selectable():
+    d = run_bench(["--config", "c1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"])
+    assert "640x480" in d["config"]["workload"] and d["n_gpus"] == 1 and 0 < d["roofline"]["frac"] < 1.0
+    d = run_bench(["--config", "c4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    assert "1024 spheres" in d["config"]["workload"] and "3840x2160" in d["config"]["workload"]
+    assert d["value"] > 1e3 and "generic_kernels" not in d
+    d = run_bench(["--gpus", "2", "--config", "c2", "--scaling", "weak", "--steps", "4", "--warmup", "1"],
+                  {"RT_BENCH_REHEARSE_WORLD": "2", "RT_BENCH_REHEARSE_RANK": "0"})
+    assert d["scaling"] == "weak" and "1920x1080" not in d["config"]["workload"]
+    d = run_bench(["--gpus", "8", "--config", "c2", "--steps", "4", "--warmup", "1"],
+                  {"RT_BENCH_REHEARSE_WORLD": "8", "RT_BENCH_REHEARSE_RANK": "3"})
+    assert d["scaling"] == "strong" and "1920x1080" in d["config"]["workload"] and d["n_gpus"] == 8
