@@ -193,7 +193,7 @@ def test_sparse_pixels_of_full_size_builtin_configs(golden, make_scene):
         xy, want = arrays[sp["key"] + "_xy"], arrays[sp["key"] + "_rad"]
         got = rad[xy[:, 1], xy[:, 0]]
         rel = (np.abs(got - want) / np.maximum(np.abs(want), 1e-3)).max(-1)
-        assert (rel <= 1e-4).mean() >= 0.99, sp["key"]
+        assert (rel <= 1e-4).all(), (sp["key"], int((rel > 1e-4).sum()))   # the exact build: every pin
 
 
 @pytest.mark.parametrize("W,H,s,d,devs", [(333, 217, 2, 5, [0, 0, 0]), (640, 480, 1, 4, [0, 0]),
@@ -575,7 +575,7 @@ def test_c4_sparse_pins_at_full_size(torch_cuda, golden, make_scene, name, W, H,
         _, rad, _ = render_dev(torch_cuda, ctx, cam, int(y), 1)
         rel = np.abs(rad[y, x] - w) / np.maximum(np.abs(w), 1e-3)
         ok += bool((rel <= 1e-4).all())
-    assert ok >= 15
+    assert ok == 16
     ctx.close()
 
 
@@ -992,4 +992,60 @@ def test_scene_upload_finishes_the_render_in_flight(torch_cuda, make_scene):
     ctx.upload(other)
     torch.cuda.synchronize()
     assert np.array_equal(argb.cpu().numpy().view(np.uint32), want)
+    ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# whole-frame pins of the big configurations (tests/golden/frames.npz, made by make_golden_frames.py)
+# ---------------------------------------------------------------------------------------------
+
+def _frames_fixture():
+    import json, os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    return json.load(open(os.path.join(here, "frames.json"))), np.load(os.path.join(here, "frames.npz"))
+
+
+def test_c3_full_frame_hash_and_counts(torch_cuda, make_scene):
+    """BASELINE config 3 (3840x2160, 4x4 samples, depth 8) at full size: the P6 file has the md5 of the
+    reference's own, and the ray / test counts equal its ld --wrap counters."""
+    meta, _ = _frames_fixture()
+    fr = [h for h in meta["hashes"] if (h["W"], h["H"]) == (3840, 2160)][0]
+    sc = make_scene("builtin")
+    cam = rt.prepare_camera(sc, 3840, 2160, 4, 8)
+    ctx = rt.Context()
+    ctx.upload(sc)
+    argb, _, st = render_dev(torch_cuda, ctx, cam)
+    assert ppm_md5(argb, 3840, 2160) == fr["md5"]
+    c = fr["counts"]
+    primary = 3840 * 2160 * 16
+    assert st.primary_rays == primary and st.shadow_rays == c["ray_create"] - primary
+    assert st.reflection_rays + st.transmission_rays == c["ray_tinypush"] - st.shadow_rays
+    _, _, st2 = render_dev(torch_cuda, ctx, cam, stats=True)
+    assert (st2.sphere_tests, st2.sphere_hits) == (c["sphere_tests"], c["sphere_hits"])
+    assert (st2.polygon_tests, st2.polygon_hits) == (c["polygon_tests"], c["polygon_hits"])
+    assert st2.polygon_screen_mismatch == 0
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["c4", "c5"])
+def test_big_scene_frames_against_the_reference(torch_cuda, make_scene, name):
+    """The scenes of configs 4 (1024 spheres + 4 quads: spheres in LDS tiles) and 5 (16 384 spheres, 8 lights,
+    depth 16: the sphere grid) as whole frames at a reduced size, against frames the reference rendered:
+    identical 8-bit pictures, radiance within 1e-4 on every pixel, ray counts equal to its counters."""
+    meta, arrays = _frames_fixture()
+    fr = [f for f in meta["frames"] if f["scene"] == name][0]
+    sc = make_scene(name)
+    cam = rt.prepare_camera(sc, fr["W"], fr["H"], fr["sqrtSpp"], fr["depth"])
+    ctx = rt.Context()
+    ctx.upload(sc)
+    argb, rad, st = render_dev(torch_cuda, ctx, cam)
+    a_ref, r_ref = arrays[fr["key"] + "_argb"], arrays[fr["key"] + "_rad"]
+    rel = (np.abs(rad - r_ref) / np.maximum(np.abs(r_ref), 1e-3)).max(-1)
+    assert (rel <= 1e-4).all(), (name, int((rel > 1e-4).sum()), float(rel.max()))
+    assert (np.abs(rgb_bytes(argb) - rgb_bytes(a_ref)).max(-1) <= 1).all()
+    assert (argb != a_ref).mean() < 1e-3              # (libm powf's last bit can move a pixel across an 8-bit step)
+    c = fr["counts"]
+    primary = fr["W"] * fr["H"] * fr["sqrtSpp"] ** 2
+    assert st.shadow_rays == c["ray_create"] - primary
+    assert st.reflection_rays + st.transmission_rays == c["ray_tinypush"] - st.shadow_rays
     ctx.close()
