@@ -271,7 +271,13 @@ int  rt_hip_tone_static(float *d_radiance, uint32_t *d_argb, uint64_t npixels, i
                         int64_t key_pixel, void *stream);
 
 /* Wait for the last rt_hip_render_rows, verify no queue overflowed (re-rendering finer
- * batches if one did) and return its counters.  stats may be NULL. */
+ * batches if one did) and return its counters.  stats may be NULL.
+ * The pixels of an asynchronous render are FINAL only after this call has returned 0: a batch whose
+ * queues overflowed is abandoned on the device (its rows keep whatever the buffers held) and is rendered
+ * again here, in halves, so work ordered behind the render on a stream may read unfinished rows when
+ * stats->overflow_retries comes back non-zero.  Contexts created with capacity 0 size their queues from
+ * the frame and do not overflow on scenes whose ray trees stay within one queue entry per primary
+ * sample and level (every BASELINE configuration). */
 int  rt_hip_finish(rt_hip_ctx *ctx, rt_hip_stats *stats);
 
 /* Same render with instrumented kernels that also count ray-object tests by outcome
