@@ -2186,7 +2186,8 @@ void rt_launch_primary_fast(const DevScene &S, const DevCamera &C, const DevWork
         grid_scene ? k_primary<true, false, false, 0>
         : rt_scene_shape(S) == 1 ? k_primary<false, false, true, 1>
         : S.tabInLds ? k_primary<false, false, true, 0> : k_primary<false, false, false, 0>;
-    kernel<<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, R);
+    static const size_t pad_to = [] { const char *e = getenv("RT_HIP_PRIMARY_LDS"); return e ? (size_t)atol(e) : 0; }(); /* as in rt_launch_primary */
+    kernel<<<grid, RT_BLOCK, lds < pad_to && pad_to <= 65536 ? pad_to : lds, stream>>>(S, C, Wk, R);
 }
 #else
 void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
