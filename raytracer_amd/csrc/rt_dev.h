@@ -39,6 +39,12 @@
 #define RT_DEV_ATOMIC(cond) (cond)
 #endif
 
+#ifdef RT_ABL_NO_LITTILE /* tiles of one lit polygon take the general sample loop */
+#define RT_DEV_LITTILE(cond) false
+#else
+#define RT_DEV_LITTILE(cond) (cond)
+#endif
+
 /* -DRT_PHASE_CLOCKS (tools/phase_probe.py, tools/phase_probe_k0.py): wave cycles per phase of k_bounce,
  * read with s_memtime, summed into the statistic slots the
  * plain build leaves unused (ST_SPH_TESTS + phase).  Compiles to nothing otherwise. */
@@ -67,3 +73,15 @@ struct PhaseClock {
 #endif
 };
 
+
+/* -DRT_TILE_CLOCKS (tools/tile_probe.py): waves and wave cycles of k_primary per class of tile, in the
+ * statistic slots the plain build leaves unused (ST_SPH_TESTS + 2 * class: waves, + 1: cycles). */
+#ifdef RT_TILE_CLOCKS
+#define RT_DEV_TILE_START() const unsigned long long tile_t0_ = clock64()
+#define RT_DEV_TILE_END(st, cls) do { if (__lane_id() == 0) { \
+    atomicAdd((unsigned long long *)&(st)[ST_SPH_TESTS + 2 * (cls)], 1ull); \
+    atomicAdd((unsigned long long *)&(st)[ST_SPH_TESTS + 2 * (cls) + 1], clock64() - tile_t0_); } } while (0)
+#else
+#define RT_DEV_TILE_START() ((void)0)
+#define RT_DEV_TILE_END(st, cls) ((void)0)
+#endif

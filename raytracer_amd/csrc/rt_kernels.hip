@@ -1581,6 +1581,87 @@ struct StashedEye {
     }
 };
 
+#ifdef RT_FAST
+/*
+ * The sample loop of a tile whose every sample hits ONE polygon, inside, sees every light from there and
+ * spawns nothing (classify_pixel: tile_polygon + tile_lit; the reference scene's floor outside the spheres'
+ * shadows, a third of its tiles) - the tolerance build only.  The object, its material, the plane, the
+ * normal and the lights are the same for all lanes and all samples: they are read once, into scalar
+ * registers, and what is left per sample is straight-line vector code with the expressions of the general
+ * path (hit point from the un-normalised direction, get_shade_color_phong raytrace.c:282-401 with every
+ * shadow ray known to be free, get_object_color object3d.c:64-117, clamp :562) - no search, no exec-mask
+ * bookkeeping, no LDS traffic.  Returns the sum of the samples' colours in the reference's order.
+ */
+template <bool TABLDS>
+__device__ __forceinline__ void lit_polygon_tile(const DevScene &S, const DevCamera &C, const float4 *lds_poly,
+                                                 const float *cam, const float *kc, const Tables<TABLDS> &tab,
+                                                 uint32_t polygon, uint32_t rec, float fu0, float fv0,
+                                                 float &accr, float &accg, float &accb)
+{
+    auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+    const float4 pl4 = lds_poly[polygon];
+    const float plx = uni(pl4.x), ply = uni(pl4.y), plz = uni(pl4.z), plw = uni(pl4.w);
+    const float ox = uni(cam[CAM_EYE + 0]), oy = uni(cam[CAM_EYE + 1]), oz = uni(cam[CAM_EYE + 2]);
+    const float num = -1.0f * (dot3(plx, ply, plz, ox, oy, oz) + plw);
+    const float4 mA = tab[rec + RT_OBJ_DIFFUSE], mB = tab[rec + RT_OBJ_SPECULAR], mC = tab[rec + RT_OBJ_PHONG];
+    const float4 gE = tab[rec + RT_OBJ_SHAPE];
+    const float ka = uni(mA.w), kd = uni(mC.x), ke = uni(mC.y), ks = uni(mB.w);
+    const float sr = uni(mB.x), sg = uni(mB.y), sb = uni(mB.z);
+    const float Nx = uni(gE.x), Ny = uni(gE.y), Nz = uni(gE.z);
+    const float ar = uni(kc[KC_AMBIENT + 0]), ag = uni(kc[KC_AMBIENT + 1]), ab = uni(kc[KC_AMBIENT + 2]);
+    const float Ux = uni(cam[CAM_U + 0]), Uy = uni(cam[CAM_U + 1]), Uz = uni(cam[CAM_U + 2]);
+    const float Vx_ = uni(cam[CAM_V + 0]), Vy_ = uni(cam[CAM_V + 1]), Vz_ = uni(cam[CAM_V + 2]);
+    const float Sx = uni(cam[CAM_SHIFTN + 0]), Sy = uni(cam[CAM_SHIFTN + 1]), Sz = uni(cam[CAM_SHIFTN + 2]);
+    const float spph = uni(cam[CAM_SPPHALF]), sppw = uni(cam[CAM_SPPW]);
+    for (uint32_t j = 0; j < C.sqrtSpp; ++j) {
+        const float fv = fv0 + (spph + (float)j * sppw);
+        for (uint32_t i = 0; i < C.sqrtSpp; ++i) {
+            const float fu = fu0 + (spph + (float)i * sppw);
+            const float Dx = (Sx + Ux * fu) + Vx_ * fv;
+            const float Dy = (Sy + Uy * fu) + Vy_ * fv;
+            const float Dz = (Sz + Uz * fu) + Vz_ * fv;
+            const float t = num * rcp_refined(dot3(plx, ply, plz, Dx, Dy, Dz));
+            const float px = ox + Dx * t, py = oy + Dy * t, pz = oz + Dz * t;
+            float Vx = ox - px, Vy = oy - py, Vz = oz - pz; /* raytrace.c:318-320 */
+            normalize3(Vx, Vy, Vz);
+            float dfr = 0.f, dfg = 0.f, dfb = 0.f, spr = 0.f, spg = 0.f, spb = 0.f;
+            for (uint32_t l = 0; l < S.nLights; ++l) { /* raytrace.c:349-384, every light visible */
+                const float4 lp = tab[2u * l];
+                const float4 lc = tab[2u * l + 1u];
+                float sx = lp.x - px, sy = lp.y - py, sz = lp.z - pz;
+                float len, inv;
+                length_and_reciprocal(sx, sy, sz, len, inv);
+                sx = sx * inv; sy = sy * inv; sz = sz * inv;
+                const float c = dot3(sx, sy, sz, Nx, Ny, Nz);
+                const bool dark = c <= 0.0f;
+                const float cp = dark ? 0.0f : c;
+                dfr += lc.x * cp; dfg += lc.y * cp; dfb += lc.z * cp;
+                const float c2 = 2.0f * c;
+                const float Rx = Nx * c2 - sx, Ry = Ny * c2 - sy, Rz = Nz * c2 - sz;
+                float h = dot3(Rx, Ry, Rz, Vx, Vy, Vz);
+                if (h < 0.0f)
+                    h = 0.0f;
+                h = dark ? 0.0f : phong_pow(h, ke);
+                spr += lc.x * h; spg += lc.y * h; spb += lc.z * h;
+            }
+            /* get_object_color object3d.c:64-117: the checkerboard every polygon gets */
+            const float u = div_with(px + 15.0f, 22.0f, 1.0f / 22.0f);
+            const float v = div_with(pz + 100.0f, 100.0f, 1.0f / 100.0f);
+            const int xt = (int)(11.0f * u);
+            const int yt = (int)(50.0f * v);
+            const float ocg = ((xt % 2) == (yt % 2)) ? 0.0f : 1.0f; /* (red 1, blue 0) */
+            float outr = ar * ka, outg = (ocg * ag) * ka, outb = (0.0f * ab) * ka; /* raytrace.c:303-307 */
+            outr += kd * dfr + (ks * spr) * sr; /* raytrace.c:390-401 */
+            outg += (kd * dfg) * ocg + (ks * spg) * sg;
+            outb += (kd * dfb) * 0.0f + (ks * spb) * sb;
+            accr = accr + clamp1(outr); /* raytrace.c:562, 774 */
+            accg = accg + clamp1(outg);
+            accb = accb + clamp1(outb);
+        }
+    }
+}
+#endif
+
 template <bool STATS>
 __device__ __forceinline__ void flush_tally(uint64_t *st, Tally<STATS> &tl, bool k0)
 {
@@ -1634,6 +1715,7 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
                                                       DevRows R)
 {
     fix_shape<SHAPE>(S);
+    RT_DEV_TILE_START();
     extern __shared__ __attribute__((aligned(16))) float4 lds[];
     float *lds_park = (float *)lds; /* RT_PARK_FLOATS, ahead of the scene data */
     float4 *lds_poly = lds + RT_PARK_FLOATS / 4u;
@@ -1711,10 +1793,30 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
                 Wk.pixAcc[pix] = make_float4(accr, accg, accb, __uint_as_float(0u));
             wave_add_total((uint64_t *)(Wk.counters + CNT_STATS + shard * CNT_STATS_STRIDE), ST_K0_CULLED,
                            (uint32_t)__popcll(__ballot(valid)) * C.sqrtSpp * C.sqrtSpp);
+            RT_DEV_TILE_END((uint64_t *)(Wk.counters + CNT_STATS + shard * CNT_STATS_STRIDE), 0);
             return;
         }
     }
 
+#ifdef RT_FAST
+    if constexpr (!BLINN && !STATS) {
+        if (RT_DEV_LITTILE(tile_polygon != RT_NONE && tile_lit)) { /* wave-uniform */
+            const uint32_t pobj = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(lds_poly[S.nPoly + tile_polygon].z));
+            const uint32_t prec = 2u * S.nLights + pobj * (uint32_t)RT_OBJ_FIELDS;
+            const float4 mC = tab[prec + RT_OBJ_PHONG];
+            const bool spawns = __builtin_amdgcn_readfirstlane((int)((mC.z != 0.0f || mC.w != 0.0f) && C.depth != 0u)) != 0;
+            if (!spawns) { /* raytrace.c:405,452 */
+                lit_polygon_tile<TABLDS>(S, C, lds_poly, cam, kc, tab, tile_polygon, prec, fu0, fv0, accr, accg, accb);
+                if (valid)
+                    Wk.pixAcc[pix] = make_float4(accr, accg, accb, __uint_as_float(0u));
+                wave_add_total((uint64_t *)(Wk.counters + CNT_STATS + shard * CNT_STATS_STRIDE), ST_K0_SHADE_NODES,
+                               (uint32_t)__popcll(__ballot(valid)) * C.sqrtSpp * C.sqrtSpp);
+                RT_DEV_TILE_END((uint64_t *)(Wk.counters + CNT_STATS + shard * CNT_STATS_STRIDE), 1);
+                return;
+            }
+        }
+    }
+#endif
     for (uint32_t j = 0; j < C.sqrtSpp; ++j) {
         for (uint32_t i = 0; i < C.sqrtSpp; ++i) {
             float px, py, pz;
@@ -1787,6 +1889,7 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
     wave_add_total(st, ST_K0_REFL, sc.refl);
     wave_add_total(st, ST_K0_TRANS, sc.trans);
     flush_tally<STATS>(st, tl, true);
+    RT_DEV_TILE_END(st, tile_polygon != RT_NONE ? 2 : tile_no_spheres ? 3 : 4);
 }
 
 /* ------------------------------------------------------------------------------------------ */
