@@ -1181,6 +1181,11 @@ static int submit(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb, float *
         /* one entry per primary sample of the job (the batch plan's rule), within [1 Mi, the limit]; the
          * blob only ever grows */
         uint64_t want = (uint64_t)job.ntiles * 8u * c->C.W * c->C.sqrtSpp * c->C.sqrtSpp;
+        /* ... times what the last frame of this shape needed per sample, if that was more (mirror-heavy
+         * scenes): every batch pays the latency of its sparse deep levels once, config 5's scene ~14 ms of
+         * a 75 ms frame when it was cut in two */
+        if (c->seen_valid && c->seen_density * 1.15 > 1.0)
+            want = (uint64_t)((double)want * c->seen_density * 1.15) + 1u;
         want = round_cap(want < (1ull << 20) ? (1ull << 20) : want > c->cap_limit ? c->cap_limit : want);
         if (want > c->cap && (rc = ensure_work(c, want)))
             return rc;

@@ -613,7 +613,8 @@ def test_grid_search_equals_the_loop_over_every_sphere(torch_cuda, make_scene):
         ax = rng.random(n) < 0.05
         d[ax] = np.eye(3)[rng.integers(0, 3, ax.sum())] * rng.choice([-1, 1], ax.sum())[:, None]
         d /= np.linalg.norm(d, axis=1, keepdims=True)
-        d *= rng.choice([1.0, 1.0, 1.0, 0.9, 1.08, 1.0 + 3e-7], n)[:, None]
+        # (longer than unit: the cone walk up to 24 degrees - n = 0.95 gives |d| <= 1.098 -, the loop beyond)
+        d *= rng.choice([1.0, 1.0, 1.0, 0.9, 1.08, 1.0 + 3e-7, 1.004, 1.03, 1.098, 1.3, 1.9], n)[:, None]
         mag = rng.choice([9999999.9, 99999.9, 30.0, 5.0], n)
         rays = torch.from_numpy(np.concatenate([o, d, mag[:, None]], 1).astype(np.float32)).cuda().contiguous()
         out = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
