@@ -846,6 +846,43 @@ def test_deep_folds_in_one_launch_change_nothing(torch_cuda, make_scene, name, W
     ctx.close()
 
 
+def test_contexts_size_themselves_from_their_frames(torch_cuda, make_scene):
+    """rt_hip_ctx_create with capacity 0: the queues are sized when a render is submitted - one entry per
+    primary sample of the job, and from the second frame of a shape on what that shape needed per sample
+    (mirror-heavy scenes queue more than one hit per sample), so that the frame is ONE batch: every batch
+    pays the latency of its sparse deep levels.  Pixels and counters never depend on the batching."""
+    torch = torch_cuda
+    sc = make_scene("c5")
+    W, H, s, d = 960, 540, 2, 16  # 2.07 M samples: above the 1 Mi entries a context starts with
+    cam = rt.prepare_camera(sc, W, H, s, d)
+    ref = rt.Context(queue_cap=1 << 24)
+    ref.upload(sc)
+    want, want_rad, st0 = render_dev(torch, ref, cam)
+    ref.close()
+    assert st0.batches == 1 and st0.overflow_retries == 0
+    ctx = rt.Context()  # capacity 0
+    ctx.upload(sc)
+    seen = []
+    for _ in range(3):
+        argb, rad, st = render_dev(torch, ctx, cam)
+        assert np.array_equal(argb, want) and np.array_equal(rad.view(np.uint32), want_rad.view(np.uint32))
+        assert (st.shade_nodes, st.reflection_rays, st.transmission_rays) == \
+            (st0.shade_nodes, st0.reflection_rays, st0.transmission_rays)
+        seen.append((st.batches, st.overflow_retries))
+    assert seen[0][0] > 1 or seen[0][1] > 0, seen  # the scene does need more than an entry per sample ...
+    assert seen[1] == (1, 0) and seen[2] == (1, 0), seen  # ... and the context has grown to it
+    # a small frame on the same context: still one batch, same pixels as a context of its own
+    small = rt.prepare_camera(sc, 96, 64, 1, 3)
+    a1, r1, st1 = render_dev(torch, ctx, small)
+    fresh = rt.Context()
+    fresh.upload(sc)
+    a2, r2, st2 = render_dev(torch, fresh, small)
+    assert st1.batches == 1 and st2.batches == 1
+    assert np.array_equal(a1, a2) and np.array_equal(r1.view(np.uint32), r2.view(np.uint32))
+    fresh.close()
+    ctx.close()
+
+
 def test_tail_stream_changes_nothing(torch_cuda, make_scene):
     """rt_hip_ctx_set_tail_stream: the sparse levels, folds and resolve of every batch on a second stream.
     Same pixels, radiance bits and counters as on one stream - for a single batch, for a frame cut into
