@@ -1506,7 +1506,7 @@ __device__ __forceinline__ PixelView classify_pixel(const DevScene &S, const flo
             const float rho = 1.5f * tc * eta * (1.0f + nlen * __builtin_amdgcn_rcpf(fabsf(q)));
             const float move = info.w * rho + 1e-3f; /* info.w = gmax */
             verdict = (gmin - move >= 0.0f) ? 1 : ((gmin + move <= -1.0f) ? -1 : 0);
-            if (kFast && !GRID && verdict > 0 && inside == RT_NONE) { /* shadow rays of this polygon's hits */
+            if (!GRID && verdict > 0 && inside == RT_NONE) { /* shadow rays of this polygon's hits */
                 lit = true;
                 for (uint32_t l = 0; l < S.nLights; ++l) {
                     const float4 lp = tab[2u * l];
@@ -1774,8 +1774,9 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
         const PixelView pv = classify_pixel<GRID, TABLDS>(S, cam, lds_poly, lds_sph, tab, fu0, fv0, C.sqrtSpp);
         const bool nothing = !valid || (!pv.spheres && !pv.unsure && pv.inside == RT_NONE);
         tile_no_spheres = __all(!valid || !pv.spheres);
-        if constexpr (kFast && !BLINN) {
-            /* (the tolerance build only: the hit point is formed without normalising the direction) */
+        if constexpr (!BLINN) {
+            /* (the exact build uses tile_polygon for tile_lit alone: only the tolerance build forms the hit
+             * point without normalising the direction) */
             const unsigned long long live = __ballot(valid);
             const uint32_t first = live ? (uint32_t)__builtin_amdgcn_readlane((int)pv.inside, __ffsll((long long)live) - 1) : RT_NONE;
             if (tile_no_spheres && first != RT_NONE && __all(!valid || (pv.inside == first && !pv.unsure))) {
