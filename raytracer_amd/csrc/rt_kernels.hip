@@ -112,6 +112,14 @@ __device__ __forceinline__ void wave_add_stat(uint64_t *stats, int slot, uint32_
 }
 
 /* vec4_magnitude vector4.c:219-233: (float)sqrt((double)float_sum) == correctly rounded sqrtf */
+/* a float4 every lane reads from the same read-only address: through the scalar cache into scalar registers */
+__device__ __forceinline__ float4 const_load4(const float4 *p)
+{
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v v = *((const __attribute__((address_space(4))) f4v *)(uintptr_t)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 __device__ __forceinline__ float mag3(float x, float y, float z)
 {
     return sqrt_rn((x * x + y * y) + z * z);
@@ -731,7 +739,9 @@ __device__ __forceinline__ void intersect_all(const DevScene &S, const float4 *l
         }
         if (!(BIG && ANYHIT && !STATS && found)) {
             for (; j < cnt; ++j) {
-                const float4 s = EYE ? eye_terms[j] : lds_sph[j]; /* same address in all lanes: LDS broadcast */
+                /* (same address in all lanes: the eye terms as an LDS broadcast, the spheres themselves through
+                 * the scalar cache - a wave-wide 16-byte LDS read occupies the CU's LDS pipeline for 8 cycles) */
+                const float4 s = EYE ? eye_terms[j] : const_load4(S.sph + j);
                 if (FILTERED && j == exc_sph)
                     continue;
                 tl.sph_test();
@@ -759,7 +769,7 @@ __device__ __forceinline__ void intersect_all(const DevScene &S, const float4 *l
             if (FILTERED && p == exc_poly)
                 continue;
             tl.poly_test();
-            const float4 pl = lds_poly[p];
+            const float4 pl = const_load4(S.poly + p);
             /* ray.c:92-117 */
             const float num = EYE ? eye_terms[S.nSph + p].x
                                   : -1.0f * (dot3(pl.x, pl.y, pl.z, r.ox, r.oy, r.oz) + pl.w);
@@ -774,7 +784,7 @@ __device__ __forceinline__ void intersect_all(const DevScene &S, const float4 *l
                 continue;
             }
             tl.poly_full();
-            const float4 info = lds_poly[S.nPoly + p];
+            const float4 info = const_load4(S.poly + S.nPoly + p);
             const uint32_t pobj = __float_as_uint(info.z);
             /* would this hit be taken at all?  (skips the angle sum when it cannot matter) */
             bool wins;
