@@ -453,9 +453,18 @@ __host__ __device__ __forceinline__ uint32_t sphere_slots(uint32_t nSph)
     return nSph > RT_TILE_SPHERES ? 0u : nSph + (nSph + 3u) / 4u; /* (big scenes walk a grid in HBM) */
 }
 
-__device__ __forceinline__ void block_copy(float4 *dst, const float4 *src, uint32_t n)
+/* Who stages a block's LDS: all its threads together (the default), or - kernels whose sky waves leave before
+ * the staging (k_primary of the reference's scene shape) - every wave the whole of it on its own: the waves
+ * that are left cannot know which others are, the data is a few hundred bytes, and identical values written
+ * twice to the same address are harmless. */
+struct Stagers {
+    uint32_t tid, stride;
+    __device__ __forceinline__ static Stagers block() { return {threadIdx.x, RT_BLOCK}; }
+    __device__ __forceinline__ static Stagers wave() { return {threadIdx.x & 63u, 64u}; }
+};
+__device__ __forceinline__ void block_copy(float4 *dst, const float4 *src, uint32_t n, Stagers st = Stagers::block())
 {
-    for (uint32_t i = threadIdx.x; i < n; i += RT_BLOCK)
+    for (uint32_t i = st.tid; i < n; i += st.stride)
         dst[i] = src[i];
 }
 
@@ -832,11 +841,11 @@ template <bool TABLDS> struct Tables {
 };
 /* callers follow up with __syncthreads() */
 template <bool TABLDS>
-__device__ __forceinline__ Tables<TABLDS> stage_tables(const DevScene &S, uint32_t *lds_vis)
+__device__ __forceinline__ Tables<TABLDS> stage_tables(const DevScene &S, uint32_t *lds_vis, Stagers st = Stagers::block())
 {
     if constexpr (TABLDS) {
         float4 *lds_tab = (float4 *)(lds_vis + vis_words(S.nLights));
-        block_copy(lds_tab, S.tab, S.tabSlots);
+        block_copy(lds_tab, S.tab, S.tabSlots, st);
         return Tables<TABLDS>{lds_tab};
     } else {
         return Tables<TABLDS>{S.tab};
@@ -846,9 +855,9 @@ __device__ __forceinline__ Tables<TABLDS> stage_tables(const DevScene &S, uint32
 /* Scene colours every shade needs (background, ambient light), in LDS rather than in scalar registers (the trace
  * kernels run out of them and spill into VGPR lanes) */
 enum { KC_BG = 0, KC_AMBIENT = 3, KC_WORDS = 8 };
-__device__ __forceinline__ void stage_colours(const DevScene &S, float *kc)
+__device__ __forceinline__ void stage_colours(const DevScene &S, float *kc, Stagers st = Stagers::block())
 {
-    if (threadIdx.x == 0)
+    if (st.tid == 0)
         for (int k = 0; k < 3; ++k) {
             kc[KC_BG + k] = S.bg[k];
             kc[KC_AMBIENT + k] = S.ambient[k];
@@ -859,10 +868,10 @@ __device__ __forceinline__ void stage_colours(const DevScene &S, float *kc)
  * ray.c:185-195 and ray.c:92-95 with origin = eye.  Needs lds_sph / lds_poly staged (barrier before),
  * callers follow up with __syncthreads(). */
 __device__ __forceinline__ void stage_eye_terms(const DevScene &S, const DevCamera &C, const float4 *lds_poly,
-                                                const float4 *lds_sph, float4 *eye_terms)
+                                                const float4 *lds_sph, float4 *eye_terms, Stagers st = Stagers::block())
 {
     const float ox = C.eye[0], oy = C.eye[1], oz = C.eye[2];
-    for (uint32_t k = threadIdx.x; k < S.nSph + S.nPoly; k += RT_BLOCK) {
+    for (uint32_t k = st.tid; k < S.nSph + S.nPoly; k += st.stride) {
         if (k < S.nSph) {
             const float4 s = lds_sph[k];
             const float ex = ox - s.x, ey = oy - s.y, ez = oz - s.z;
@@ -1379,9 +1388,9 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
  * rather than in ~16 scalar registers for the whole kernel: the trace kernels run out of SGPRs and
  * spill them into VGPR lanes. */
 enum { CAM_EYE = 0, CAM_U = 3, CAM_V = 6, CAM_SHIFTN = 9, CAM_SPPHALF = 12, CAM_SPPW = 13, CAM_WORDS = 16 };
-__device__ __forceinline__ void stage_camera(const DevCamera &C, float *cam)
+__device__ __forceinline__ void stage_camera(const DevCamera &C, float *cam, Stagers st = Stagers::block())
 {
-    if (threadIdx.x == 0) {
+    if (st.tid == 0) {
         for (int k = 0; k < 3; ++k) {
             cam[CAM_EYE + k] = C.eye[k];
             cam[CAM_U + k] = C.U[k];
@@ -1443,30 +1452,55 @@ struct PixelView {
                          more than its radius + the footprint's radius from the line (centre hit, light) is
                          missed by every line (hit, light) - with the margin of the sphere test above        */
 };
-template <bool GRID, bool TABLDS>
-__device__ __forceinline__ PixelView classify_pixel(const DevScene &S, const float *cam, const float4 *lds_poly,
-                                                    const float4 *lds_sph, const Tables<TABLDS> &tab, float fu0,
+/* where classify_pixel reads the scene from: the block's LDS copy, or - before anything is staged - the kernel
+ * arguments and the scene blob through the scalar cache (every address is the same in all lanes) */
+template <bool TABLDS> struct LdsSource {
+    const float *cam_;
+    const float4 *poly_, *sph_;
+    const Tables<TABLDS> &tab_;
+    const float *kc_;
+    __device__ __forceinline__ float kc(uint32_t i) const { return kc_[i]; }
+    __device__ __forceinline__ float cam(uint32_t i) const { return cam_[i]; }
+    __device__ __forceinline__ float4 poly(uint32_t i) const { return poly_[i]; }
+    __device__ __forceinline__ float4 sph(uint32_t i) const { return sph_[i]; }
+    __device__ __forceinline__ float4 tab(uint32_t i) const { return tab_[i]; }
+};
+struct ArgSource {
+    const DevScene &S;
+    const DevCamera &C;
+    __device__ __forceinline__ float cam(uint32_t i) const
+    {
+        return i < CAM_U ? C.eye[i - CAM_EYE] : i < CAM_V ? C.U[i - CAM_U] : i < CAM_SHIFTN ? C.V[i - CAM_V]
+               : i < CAM_SPPHALF ? C.shiftN[i - CAM_SHIFTN] : i == CAM_SPPHALF ? C.sppHalf : C.sppW;
+    }
+    __device__ __forceinline__ float kc(uint32_t i) const { return i < KC_AMBIENT ? S.bg[i - KC_BG] : S.ambient[i - KC_AMBIENT]; }
+    __device__ __forceinline__ float4 poly(uint32_t i) const { return const_load4(S.poly + i); }
+    __device__ __forceinline__ float4 sph(uint32_t i) const { return const_load4(S.sph + i); }
+    __device__ __forceinline__ float4 tab(uint32_t i) const { return const_load4(S.tab + i); }
+};
+template <bool GRID, class Source>
+__device__ __forceinline__ PixelView classify_pixel(const DevScene &S, const Source &src, float fu0,
                                                     float fv0, uint32_t sqrtSpp)
 {
     PixelView pv;
     pv.spheres = true; pv.unsure = true; pv.inside = RT_NONE; pv.lit = false;
-    const float half = 0.5f * (float)sqrtSpp * cam[CAM_SPPW];
+    const float half = 0.5f * (float)sqrtSpp * src.cam(CAM_SPPW);
     const float fu = fu0 + half, fv = fv0 + half;
-    const float Dx = (cam[CAM_SHIFTN + 0] + cam[CAM_U + 0] * fu) + cam[CAM_V + 0] * fv;
-    const float Dy = (cam[CAM_SHIFTN + 1] + cam[CAM_U + 1] * fu) + cam[CAM_V + 1] * fv;
-    const float Dz = (cam[CAM_SHIFTN + 2] + cam[CAM_U + 2] * fu) + cam[CAM_V + 2] * fv;
+    const float Dx = (src.cam(CAM_SHIFTN + 0) + src.cam(CAM_U + 0) * fu) + src.cam(CAM_V + 0) * fv;
+    const float Dy = (src.cam(CAM_SHIFTN + 1) + src.cam(CAM_U + 1) * fu) + src.cam(CAM_V + 1) * fv;
+    const float Dz = (src.cam(CAM_SHIFTN + 2) + src.cam(CAM_U + 2) * fu) + src.cam(CAM_V + 2) * fv;
     const float D2 = dot3(Dx, Dy, Dz, Dx, Dy, Dz);
     if (!(D2 > 1e-20f))
         return pv;
     const float invD = __builtin_amdgcn_rsqf(D2);
     const float dcx = Dx * invD, dcy = Dy * invD, dcz = Dz * invD;
-    const float lenU = __builtin_amdgcn_sqrtf(dot3(cam[CAM_U + 0], cam[CAM_U + 1], cam[CAM_U + 2], cam[CAM_U + 0], cam[CAM_U + 1], cam[CAM_U + 2]));
-    const float lenV = __builtin_amdgcn_sqrtf(dot3(cam[CAM_V + 0], cam[CAM_V + 1], cam[CAM_V + 2], cam[CAM_V + 0], cam[CAM_V + 1], cam[CAM_V + 2]));
+    const float lenU = __builtin_amdgcn_sqrtf(dot3(src.cam(CAM_U + 0), src.cam(CAM_U + 1), src.cam(CAM_U + 2), src.cam(CAM_U + 0), src.cam(CAM_U + 1), src.cam(CAM_U + 2)));
+    const float lenV = __builtin_amdgcn_sqrtf(dot3(src.cam(CAM_V + 0), src.cam(CAM_V + 1), src.cam(CAM_V + 2), src.cam(CAM_V + 0), src.cam(CAM_V + 1), src.cam(CAM_V + 2)));
     /* |d - dc| <= |D - Dc| / |Dc| for unit vectors made from D, Dc (times 1 / (1 - x/2) <= 1.13 for the x < 0.22 admitted below) */
     const float eta = 1.15f * ((lenU + lenV) * fabsf(half)) * invD + 1e-6f;
     if (!(eta < 0.25f))
         return pv;
-    const float ox = cam[CAM_EYE + 0], oy = cam[CAM_EYE + 1], oz = cam[CAM_EYE + 2];
+    const float ox = src.cam(CAM_EYE + 0), oy = src.cam(CAM_EYE + 1), oz = src.cam(CAM_EYE + 2);
     bool spheres = false;
     if constexpr (GRID) {
         /* Big scenes: one test against the ball around the grid's box, which holds every sphere whole.  A
@@ -1484,7 +1518,7 @@ __device__ __forceinline__ PixelView classify_pixel(const DevScene &S, const flo
         spheres = !(m > R + 5e-3f * (E + R));
     }
     for (uint32_t k = 0; k < (GRID ? 0u : S.nSph); ++k) {
-        const float4 sp = lds_sph[k]; /* (centre, r^2) */
+        const float4 sp = src.sph(k); /* (centre, r^2) */
         const float ex = ox - sp.x, ey = oy - sp.y, ez = oz - sp.z;
         const float e2 = dot3(ex, ey, ez, ex, ey, ez);
         const float t = dot3(ex, ey, ez, dcx, dcy, dcz);
@@ -1495,7 +1529,7 @@ __device__ __forceinline__ PixelView classify_pixel(const DevScene &S, const flo
     bool unsure = false, lit = false;
     uint32_t inside = RT_NONE;
     for (uint32_t k = 0; k < S.nPoly; ++k) {
-        const float4 pl = lds_poly[k]; /* (A, B, C, F) */
+        const float4 pl = src.poly(k); /* (A, B, C, F) */
         const float num = -1.0f * (dot3(pl.x, pl.y, pl.z, ox, oy, oz) + pl.w);
         const float q = dot3(pl.x, pl.y, pl.z, dcx, dcy, dcz);
         const float nlen = __builtin_amdgcn_sqrtf(dot3(pl.x, pl.y, pl.z, pl.x, pl.y, pl.z)) * 1.0001f;
@@ -1505,26 +1539,26 @@ __device__ __forceinline__ PixelView classify_pixel(const DevScene &S, const flo
             continue; /* behind the eye for every sample */
         int verdict = 0; /* +1: every sample inside, -1: every sample outside */
         if (sane && !opposite && fabsf(q) > nlen * (4.0f * eta + 1e-4f)) {
-            const float4 info = lds_poly[S.nPoly + k];
+            const float4 info = src.poly(S.nPoly + k);
             const uint32_t nv = __float_as_uint(info.y);
-            const float4 *edg = lds_poly + 2 * S.nPoly + __float_as_uint(info.x) + ((S.nPolySlots - 2u * S.nPoly) >> 1);
+            const uint32_t edg = 2u * S.nPoly + __float_as_uint(info.x) + ((S.nPolySlots - 2u * S.nPoly) >> 1); /* first edge equation */
             const float tc = num * __builtin_amdgcn_rcpf(q);
             const float pcx = ox + dcx * tc, pcy = oy + dcy * tc, pcz = oz + dcz * tc;
             float gmin = 3.0e38f;
             for (uint32_t i = 0; i < nv; ++i)
-                gmin = fminf(gmin, edge_value(edg[i], pcx, pcy, pcz));
+                gmin = fminf(gmin, edge_value(src.poly(edg + i), pcx, pcy, pcz));
             const float rho = 1.5f * tc * eta * (1.0f + nlen * __builtin_amdgcn_rcpf(fabsf(q)));
             const float move = info.w * rho + 1e-3f; /* info.w = gmax */
             verdict = (gmin - move >= 0.0f) ? 1 : ((gmin + move <= -1.0f) ? -1 : 0);
             if (!GRID && verdict > 0 && inside == RT_NONE) { /* shadow rays of this polygon's hits */
                 lit = true;
                 for (uint32_t l = 0; l < S.nLights; ++l) {
-                    const float4 lp = tab[2u * l];
+                    const float4 lp = src.tab(2u * l);
                     const float lx = lp.x - pcx, ly = lp.y - pcy, lz = lp.z - pcz;
                     const float il = __builtin_amdgcn_rsqf(dot3(lx, ly, lz, lx, ly, lz));
                     const float ux = lx * il, uy = ly * il, uz = lz * il;
                     for (uint32_t j = 0; j < S.nSph; ++j) {
-                        const float4 sp = lds_sph[j];
+                        const float4 sp = src.sph(j);
                         const float ex = sp.x - pcx, ey = sp.y - pcy, ez = sp.z - pcz;
                         const float e2 = dot3(ex, ey, ez, ex, ey, ez);
                         const float t = dot3(ex, ey, ez, ux, uy, uz);
@@ -1602,27 +1636,26 @@ struct StashedEye {
  * shadow ray known to be free, get_object_color object3d.c:64-117, clamp :562) - no search, no exec-mask
  * bookkeeping, no LDS traffic.  Returns the sum of the samples' colours in the reference's order.
  */
-template <bool TABLDS>
-__device__ __forceinline__ void lit_polygon_tile(const DevScene &S, const DevCamera &C, const float4 *lds_poly,
-                                                 const float *cam, const float *kc, const Tables<TABLDS> &tab,
+template <class Source>
+__device__ __forceinline__ void lit_polygon_tile(const DevScene &S, const DevCamera &C, const Source &src,
                                                  uint32_t polygon, uint32_t rec, float fu0, float fv0,
                                                  float &accr, float &accg, float &accb)
 {
     auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
-    const float4 pl4 = lds_poly[polygon];
+    const float4 pl4 = src.poly(polygon);
     const float plx = uni(pl4.x), ply = uni(pl4.y), plz = uni(pl4.z), plw = uni(pl4.w);
-    const float ox = uni(cam[CAM_EYE + 0]), oy = uni(cam[CAM_EYE + 1]), oz = uni(cam[CAM_EYE + 2]);
+    const float ox = uni(src.cam(CAM_EYE + 0)), oy = uni(src.cam(CAM_EYE + 1)), oz = uni(src.cam(CAM_EYE + 2));
     const float num = -1.0f * (dot3(plx, ply, plz, ox, oy, oz) + plw);
-    const float4 mA = tab[rec + RT_OBJ_DIFFUSE], mB = tab[rec + RT_OBJ_SPECULAR], mC = tab[rec + RT_OBJ_PHONG];
-    const float4 gE = tab[rec + RT_OBJ_SHAPE];
+    const float4 mA = src.tab(rec + RT_OBJ_DIFFUSE), mB = src.tab(rec + RT_OBJ_SPECULAR), mC = src.tab(rec + RT_OBJ_PHONG);
+    const float4 gE = src.tab(rec + RT_OBJ_SHAPE);
     const float ka = uni(mA.w), kd = uni(mC.x), ke = uni(mC.y), ks = uni(mB.w);
     const float sr = uni(mB.x), sg = uni(mB.y), sb = uni(mB.z);
     const float Nx = uni(gE.x), Ny = uni(gE.y), Nz = uni(gE.z);
-    const float ar = uni(kc[KC_AMBIENT + 0]), ag = uni(kc[KC_AMBIENT + 1]), ab = uni(kc[KC_AMBIENT + 2]);
-    const float Ux = uni(cam[CAM_U + 0]), Uy = uni(cam[CAM_U + 1]), Uz = uni(cam[CAM_U + 2]);
-    const float Vx_ = uni(cam[CAM_V + 0]), Vy_ = uni(cam[CAM_V + 1]), Vz_ = uni(cam[CAM_V + 2]);
-    const float Sx = uni(cam[CAM_SHIFTN + 0]), Sy = uni(cam[CAM_SHIFTN + 1]), Sz = uni(cam[CAM_SHIFTN + 2]);
-    const float spph = uni(cam[CAM_SPPHALF]), sppw = uni(cam[CAM_SPPW]);
+    const float ar = uni(src.kc(KC_AMBIENT + 0)), ag = uni(src.kc(KC_AMBIENT + 1)), ab = uni(src.kc(KC_AMBIENT + 2));
+    const float Ux = uni(src.cam(CAM_U + 0)), Uy = uni(src.cam(CAM_U + 1)), Uz = uni(src.cam(CAM_U + 2));
+    const float Vx_ = uni(src.cam(CAM_V + 0)), Vy_ = uni(src.cam(CAM_V + 1)), Vz_ = uni(src.cam(CAM_V + 2));
+    const float Sx = uni(src.cam(CAM_SHIFTN + 0)), Sy = uni(src.cam(CAM_SHIFTN + 1)), Sz = uni(src.cam(CAM_SHIFTN + 2));
+    const float spph = uni(src.cam(CAM_SPPHALF)), sppw = uni(src.cam(CAM_SPPW));
     for (uint32_t j = 0; j < C.sqrtSpp; ++j) {
         const float fv = fv0 + (spph + (float)j * sppw);
         for (uint32_t i = 0; i < C.sqrtSpp; ++i) {
@@ -1636,8 +1669,8 @@ __device__ __forceinline__ void lit_polygon_tile(const DevScene &S, const DevCam
             normalize3(Vx, Vy, Vz);
             float dfr = 0.f, dfg = 0.f, dfb = 0.f, spr = 0.f, spg = 0.f, spb = 0.f;
             for (uint32_t l = 0; l < S.nLights; ++l) { /* raytrace.c:349-384, every light visible */
-                const float4 lp = tab[2u * l];
-                const float4 lc = tab[2u * l + 1u];
+                const float4 lp = src.tab(2u * l);
+                const float4 lc = src.tab(2u * l + 1u);
                 float sx = lp.x - px, sy = lp.y - py, sz = lp.z - pz;
                 float len, inv;
                 length_and_reciprocal(sx, sy, sz, len, inv);
@@ -1726,34 +1759,10 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
 {
     fix_shape<SHAPE>(S);
     RT_DEV_TILE_START();
-    extern __shared__ __attribute__((aligned(16))) float4 lds[];
-    float *lds_park = (float *)lds; /* RT_PARK_FLOATS, ahead of the scene data */
-    float4 *lds_poly = lds + RT_PARK_FLOATS / 4u;
-    float4 *lds_sph = lds_poly + S.nPolySlots;
-    uint32_t *lds_vis = (uint32_t *)(lds_sph + sphere_slots(S.nSph));
-    const Tables<TABLDS> tab = stage_tables<TABLDS>(S, lds_vis);
-    __shared__ float cam[CAM_WORDS];
-    __shared__ float kc[KC_WORDS];
-    stage_camera(C, cam);
-    stage_colours(S, kc);
-    block_copy(lds_poly, S.poly, S.nPolySlots);
-    if (!GRID) {
-        block_copy(lds_sph, S.sph, S.nSph);
-        for (uint32_t k = threadIdx.x; k < S.nSph; k += RT_BLOCK)
-            ((uint32_t *)(lds_sph + S.nSph))[k] = S.sph_obj[k];
-    }
-    __syncthreads();
-    float4 *eye_terms = nullptr;
-    if constexpr (TABLDS) { /* small scenes: behind the shading tables */
-        eye_terms = (float4 *)(lds_vis + vis_words(S.nLights)) + S.tabSlots;
-        stage_eye_terms(S, C, lds_poly, lds_sph, eye_terms);
-        __syncthreads();
-    }
-
     /* a wave owns an 8x8 pixel tile; the block is 4 tiles side by side (32x8 pixels) */
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t x = blockIdx.x * 32u + wv * 8u + (lane & 7u);
-    const uint32_t ty = blockIdx.y; /* (tile rows top-down: centre-out, bottom-up and alternating orders all measured slower) */
+    const uint32_t ty = blockIdx.y; /* (tile rows top-down: every other order measured slower, profiles/r02_pmc_notes.md) */
     const uint32_t y = R.y_first + ty * R.y_step + (lane >> 3);
     const bool valid = (x < C.W) && (y < R.y_limit);
 
@@ -1774,14 +1783,19 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
     Tally<STATS> tl;
     PhaseClock pc; /* (development builds: cycles per phase of a sample, tools/phase_probe_k0.py) */
 
-    /* A tile none of whose pixels can see anything (sky: 40 % of the tiles of the reference's scene) is
-     * finished without tracing: spp^2 times the background colour, added in the reference's order.  The
-     * instrumented kernels trace everything (they count the reference's tests). */
+    /*
+     * What the wave's tile needs, decided from the cones of directions its pixels' samples span
+     * (classify_pixel; the instrumented kernels trace everything: they count the reference's tests).
+     * A tile none of whose pixels can see anything (sky: 59 % of the tiles of the reference's scene) is
+     * finished without tracing: spp^2 times the background colour, added in the reference's order; the
+     * tolerance build also finishes the tiles of one lit polygon here (lit_polygon_tile).  Returns true when
+     * the wave is done.
+     */
     bool tile_no_spheres = false;    /* wave-uniform: no sample of the tile can meet a sphere */
     uint32_t tile_polygon = RT_NONE; /* wave-uniform: every sample of the tile hits this polygon and nothing else */
     bool tile_lit = false;           /* wave-uniform: ... and no shadow ray from those hits can meet anything   */
-    if constexpr (!STATS) {
-        const PixelView pv = classify_pixel<GRID, TABLDS>(S, cam, lds_poly, lds_sph, tab, fu0, fv0, C.sqrtSpp);
+    auto classify_tile = [&](const auto &src) -> bool {
+        const PixelView pv = classify_pixel<GRID>(S, src, fu0, fv0, C.sqrtSpp);
         const bool nothing = !valid || (!pv.spheres && !pv.unsure && pv.inside == RT_NONE);
         tile_no_spheres = __all(!valid || !pv.spheres);
         if constexpr (!BLINN) {
@@ -1794,40 +1808,79 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
                 tile_lit = S.nPoly == 1u && S.nLights <= 32u && __all(!valid || pv.lit);
             }
         }
-        if (__all(nothing)) { /* wave-uniform; no barrier follows */
+        uint64_t *const stats = (uint64_t *)(Wk.counters + CNT_STATS + shard * CNT_STATS_STRIDE);
+        if (__all(nothing)) { /* wave-uniform */
             for (uint32_t k = 0; k < C.sqrtSpp * C.sqrtSpp; ++k) {
-                accr = accr + kc[KC_BG + 0];
-                accg = accg + kc[KC_BG + 1];
-                accb = accb + kc[KC_BG + 2];
+                accr = accr + src.kc(KC_BG + 0);
+                accg = accg + src.kc(KC_BG + 1);
+                accb = accb + src.kc(KC_BG + 2);
             }
             if (valid)
                 Wk.pixAcc[pix] = make_float4(accr, accg, accb, __uint_as_float(0u));
-            wave_add_total((uint64_t *)(Wk.counters + CNT_STATS + shard * CNT_STATS_STRIDE), ST_K0_CULLED,
-                           (uint32_t)__popcll(__ballot(valid)) * C.sqrtSpp * C.sqrtSpp);
-            RT_DEV_TILE_END((uint64_t *)(Wk.counters + CNT_STATS + shard * CNT_STATS_STRIDE), 0);
-            return;
+            wave_add_total(stats, ST_K0_CULLED, (uint32_t)__popcll(__ballot(valid)) * C.sqrtSpp * C.sqrtSpp);
+            RT_DEV_TILE_END(stats, 0);
+            return true;
         }
-    }
-
 #ifdef RT_FAST
-    if constexpr (!BLINN && !STATS) {
-        if (RT_DEV_LITTILE(tile_polygon != RT_NONE && tile_lit)) { /* wave-uniform */
-            const uint32_t pobj = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(lds_poly[S.nPoly + tile_polygon].z));
-            const uint32_t prec = 2u * S.nLights + pobj * (uint32_t)RT_OBJ_FIELDS;
-            const float4 mC = tab[prec + RT_OBJ_PHONG];
-            const bool spawns = __builtin_amdgcn_readfirstlane((int)((mC.z != 0.0f || mC.w != 0.0f) && C.depth != 0u)) != 0;
-            if (!spawns) { /* raytrace.c:405,452 */
-                lit_polygon_tile<TABLDS>(S, C, lds_poly, cam, kc, tab, tile_polygon, prec, fu0, fv0, accr, accg, accb);
-                if (valid)
-                    Wk.pixAcc[pix] = make_float4(accr, accg, accb, __uint_as_float(0u));
-                wave_add_total((uint64_t *)(Wk.counters + CNT_STATS + shard * CNT_STATS_STRIDE), ST_K0_SHADE_NODES,
-                               (uint32_t)__popcll(__ballot(valid)) * C.sqrtSpp * C.sqrtSpp);
-                RT_DEV_TILE_END((uint64_t *)(Wk.counters + CNT_STATS + shard * CNT_STATS_STRIDE), 1);
-                return;
+        if constexpr (!BLINN) {
+            if (RT_DEV_LITTILE(tile_polygon != RT_NONE && tile_lit)) { /* wave-uniform */
+                const uint32_t pobj = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(src.poly(S.nPoly + tile_polygon).z));
+                const uint32_t prec = 2u * S.nLights + pobj * (uint32_t)RT_OBJ_FIELDS;
+                const float4 mC = src.tab(prec + RT_OBJ_PHONG);
+                const bool spawns = __builtin_amdgcn_readfirstlane((int)((mC.z != 0.0f || mC.w != 0.0f) && C.depth != 0u)) != 0;
+                if (!spawns) { /* raytrace.c:405,452 */
+                    lit_polygon_tile(S, C, src, tile_polygon, prec, fu0, fv0, accr, accg, accb);
+                    if (valid)
+                        Wk.pixAcc[pix] = make_float4(accr, accg, accb, __uint_as_float(0u));
+                    wave_add_total(stats, ST_K0_SHADE_NODES, (uint32_t)__popcll(__ballot(valid)) * C.sqrtSpp * C.sqrtSpp);
+                    RT_DEV_TILE_END(stats, 1);
+                    return true;
+                }
             }
         }
-    }
 #endif
+        return false;
+    };
+    /* The kernel of the reference's scene shape classifies BEFORE anything is staged, from the kernel
+     * arguments and the scene blob through the scalar cache: the waves of the tiles finished above - two
+     * thirds of them - end without a global load waited for, an LDS word written or a barrier (a barrier
+     * waits for the waves of its block that are still alive only).  What is left of the block then stages
+     * wave by wave (Stagers). */
+    constexpr bool EARLY = SHAPE == 1 && !STATS;
+    if constexpr (EARLY) {
+        if (classify_tile(ArgSource{S, C}))
+            return;
+    }
+    const Stagers stagers = EARLY ? Stagers::wave() : Stagers::block();
+
+    extern __shared__ __attribute__((aligned(16))) float4 lds[];
+    float *lds_park = (float *)lds; /* RT_PARK_FLOATS, ahead of the scene data */
+    float4 *lds_poly = lds + RT_PARK_FLOATS / 4u;
+    float4 *lds_sph = lds_poly + S.nPolySlots;
+    uint32_t *lds_vis = (uint32_t *)(lds_sph + sphere_slots(S.nSph));
+    const Tables<TABLDS> tab = stage_tables<TABLDS>(S, lds_vis, stagers);
+    __shared__ float cam[CAM_WORDS];
+    __shared__ float kc[KC_WORDS];
+    stage_camera(C, cam, stagers);
+    stage_colours(S, kc, stagers);
+    block_copy(lds_poly, S.poly, S.nPolySlots, stagers);
+    if (!GRID) {
+        block_copy(lds_sph, S.sph, S.nSph, stagers);
+        for (uint32_t k = stagers.tid; k < S.nSph; k += stagers.stride)
+            ((uint32_t *)(lds_sph + S.nSph))[k] = S.sph_obj[k];
+    }
+    __syncthreads();
+    float4 *eye_terms = nullptr;
+    if constexpr (TABLDS) { /* small scenes: behind the shading tables */
+        eye_terms = (float4 *)(lds_vis + vis_words(S.nLights)) + S.tabSlots;
+        stage_eye_terms(S, C, lds_poly, lds_sph, eye_terms, stagers);
+        __syncthreads();
+    }
+    if constexpr (!EARLY && !STATS) {
+        if (classify_tile(LdsSource<TABLDS>{cam, lds_poly, lds_sph, tab, kc}))
+            return; /* wave-uniform; no barrier follows */
+    }
+
     for (uint32_t j = 0; j < C.sqrtSpp; ++j) {
         for (uint32_t i = 0; i < C.sqrtSpp; ++i) {
             float px, py, pz;
