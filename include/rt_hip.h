@@ -127,8 +127,9 @@ typedef struct {
     uint64_t reflection_rays;   /*                                    raytrace.c:405-431 */
     uint64_t transmission_rays; /* refracted + total-internal-refl.   raytrace.c:452-539 */
     uint64_t shade_nodes;       /* calls of get_shade_color_phong     raytrace.c:282     */
-    uint64_t tree_nodes;        /* shade nodes that spawned children (stored in HBM)     */
-    uint64_t queued_rays;       /* secondary rays that went through the HBM ray queues   */
+    uint64_t tree_nodes;        /* shade nodes that spawned children AND were stored in HBM: the sparse deep
+                                   levels of a tree are finished in registers once a context knows a frame  */
+    uint64_t queued_rays;       /* secondary-ray hits that went through the HBM queues (likewise)            */
     uint32_t batches;           /* image batches the render was split into               */
     uint32_t overflow_retries;  /* batches redone because a queue overflowed             */
     /* algorithmic work, filled only by rt_hip_render_stats (instrumented kernels):       */

@@ -217,6 +217,17 @@ uint32_t deep_entries()
     return v;
 }
 
+/* k_subtree takes the levels that hold at most this many hits per shard (RT_HIP_SUBTREE_MAX in the
+ * environment; 0 = never) */
+uint32_t subtree_entries()
+{
+    static const uint32_t v = [] {
+        const char *e = getenv("RT_HIP_SUBTREE_MAX");
+        return e && *e ? (uint32_t)strtoul(e, nullptr, 10) : 4096u;
+    }();
+    return v;
+}
+
 /* enqueue one image batch */
 int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
 {
@@ -258,33 +269,54 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
         HIP_TRY(hipStreamWaitEvent(st, c->head_done, 0));
         return 0;
     };
-    for (uint32_t d = 1; d <= depth; ++d) {
+    /* The sparse deep end of the tree - from the first level on that the last batch of this shape left
+     * with few enough hits per shard - is ONE launch in which every lane finishes the whole subtree of a
+     * hit (k_subtree): no launch per level, no nodes and no folds there.  The first render of a shape, the
+     * instrumented kernels and trees deeper than the kernel's stack take one launch per level. */
+    uint32_t sub = depth + 1u; /* first level k_subtree takes (depth + 1: none) */
+    if (c->seen_valid && !stats && c->shading == RT_SHADE_PHONG && subtree_entries() != 0u) {
+        uint32_t l = depth;
+        while (l > 2u && c->seen_hits[l - 1u] <= subtree_entries() && depth - (l - 1u) < RT_SUBTREE_LEVELS)
+            --l;
+        if (l < depth && c->seen_hits[l] <= subtree_entries() && depth - l < RT_SUBTREE_LEVELS)
+            sub = l;
+    }
+    bool moved = false;
+    for (uint32_t d = 1; d <= depth && d <= sub; ++d) {
         if (d == cut) {
             const int rc = to_tail();
             if (rc)
                 return rc;
+            moved = true;
         }
         const uint32_t expect = c->seen_valid ? (c->seen_hits[d] ? c->seen_hits[d] : 1u) : 0u;
-        if (fast)
+        if (d == sub) {
+            if (fast)
+                rt_launch_subtree_fast(c->S, c->C, Wk, d, expect, st);
+            else
+                rt_launch_subtree(c->S, c->C, Wk, d, expect, st);
+        } else if (fast) {
             rt_launch_bounce_fast(c->S, c->C, Wk, d, expect, st);
-        else
+        } else {
             rt_launch_bounce(c->S, c->C, Wk, d, stats, expect, st);
+        }
     }
-    if (cut == depth + 1u) {
+    if (cut && !moved) { /* (a cut below the last kernel launched: the folds and the resolve go to the tail) */
         const int rc = to_tail();
         if (rc)
             return rc;
     }
-    /* Nodes exist on levels 0..depth-1; level 0 folds in resolve.  The sparse deep levels - from the
-     * first level on that the last batch of this shape left with few enough nodes per shard - fold in
-     * one launch, the others in one launch each. */
-    uint32_t fold_from = depth;
-    if (c->seen_valid && deep_entries() != 0u && depth >= 3u) {
-        uint32_t bottom = depth;
+    /* Nodes exist on levels 0..depth-1 (0..sub-1 with k_subtree); level 0 folds in resolve.  The sparse
+     * deep levels - from the first level on that the last batch of this shape left with few enough nodes
+     * per shard - fold in one launch, the others in one launch each. */
+    const uint32_t node_levels = sub <= depth ? sub : depth; /* levels 0 .. node_levels - 1 hold nodes */
+    uint32_t fold_from = node_levels;
+    if (c->seen_valid && deep_entries() != 0u && node_levels >= 3u) {
+        uint32_t bottom = node_levels;
         while (bottom > 1u && c->seen_nodes[bottom - 1u] <= deep_entries())
             --bottom;
-        if (bottom + 1u < depth) { /* at least two levels */
-            rt_launch_fold_deep(Wk, depth - 1u, bottom, st);
+        if (bottom + 1u < node_levels) { /* at least two levels */
+            rt_launch_fold_deep(Wk, node_levels - 1u, bottom, st);
             fold_from = bottom;
         }
     }

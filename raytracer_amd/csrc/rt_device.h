@@ -200,6 +200,13 @@ void rt_launch_bounce_fast(const DevScene &S, const DevCamera &C, const DevWork 
  * It only sizes the grid; the kernels stride over whatever the counters say. */
 void rt_launch_bounce(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t level,
                       bool stats, uint32_t expect, hipStream_t stream);
+/* the hits queued for `level` and everything below them, depth first, in one launch (k_subtree): at most
+ * RT_SUBTREE_LEVELS levels, i.e. depth - level < RT_SUBTREE_LEVELS */
+#define RT_SUBTREE_LEVELS 8
+void rt_launch_subtree(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t level,
+                       uint32_t expect, hipStream_t stream);
+void rt_launch_subtree_fast(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t level,
+                            uint32_t expect, hipStream_t stream);
 void rt_launch_fold(const DevWork &Wk, uint32_t level, uint32_t expect, hipStream_t stream);
 void rt_launch_resolve(const DevCamera &C, const DevWork &Wk, const DevRows &R, uint32_t *d_argb,
                        float *d_radiance, hipStream_t stream);

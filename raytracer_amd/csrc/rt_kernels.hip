@@ -1004,7 +1004,17 @@ __device__ __forceinline__ void wave_add_total(uint64_t *stats, int slot, uint32
  * Returns true when the lane produced a tree node (index in node_idx); otherwise `leaf` holds
  * the clamped colour of a childless node.
  */
-template <bool GRID, bool STATS, bool TABLDS, bool BLINN = false, typename EyeSource>
+/* what shade_and_spawn hands back in its DFS mode (k_subtree) instead of making a node and queueing the
+ * children's hits: the node's own colour and coefficients, which children it asked for and which of them hit
+ * something, and the transmission child's ray and hit (the reflection child's are parked in LDS rows 7-16) */
+struct DfsNode {
+    float r, g, b, kr, kt;
+    bool want_r, want_t, hit_r, hit_t;
+    Ray t_ray;
+    float t_dist;
+    uint32_t t_obj;
+};
+template <bool GRID, bool STATS, bool TABLDS, bool BLINN = false, bool DFS = false, typename EyeSource>
 __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCamera &C,
                                                 const DevWork &Wk, const float4 *lds_poly,
                                                 float4 *lds_sph, uint32_t *lds_vis, float *lds_park,
@@ -1014,7 +1024,7 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
                                                 uint32_t link, uint32_t shard, uint32_t node_base,
                                                 uint32_t node_room, float leaf[3], uint32_t &node_idx,
                                                 bool &spawn_r, bool &spawn_t, Tally<STATS> &tl,
-                                                PhaseClock &pc, bool all_lit = false)
+                                                PhaseClock &pc, bool all_lit = false, DfsNode *dfs = nullptr)
 {
     /* all_lit (wave-uniform): the caller has shown that no shadow ray of this wave's hits can meet anything
      * (classify_pixel: one polygon in the scene, every sphere clear of every line from a hit to a light) */
@@ -1340,6 +1350,16 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     }
 
     pc.mark(4);
+    if constexpr (DFS) { /* the caller goes on with the children itself: no node, no queue entries */
+        dfs->r = outr; dfs->g = outg; dfs->b = outb;
+        dfs->kr = kr2; dfs->kt = kt2;
+        dfs->want_r = want_r; dfs->want_t = want_t;
+        dfs->hit_r = hit_r; dfs->hit_t = hit_t;
+        dfs->t_ray = cr;
+        dfs->t_dist = cd;
+        dfs->t_obj = cobj;
+        return true;
+    }
     /* tree node + queue slots for the children that hit: one reservation per wave */
     uint32_t *cnt = Wk.counters;
     uint32_t local, slot_r, slot_t;
@@ -2074,6 +2094,166 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_BOUNCE1 : RT_WPE)) v
     flush_tally<STATS>(st, tl, false);
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* k_subtree: the sparse deep end of the ray tree in ONE launch                                  */
+/* ------------------------------------------------------------------------------------------ */
+/*
+ * The levels from `level` on hold a few per cent of the rays of the reference's scene and used to cost a
+ * launch each (bounce) plus their folds: ~60 us of launch and per-hit latency.  Here a lane takes one hit
+ * queued for `level` and finishes its WHOLE subtree itself, depth first: shade the hit (shade_and_spawn in
+ * its DFS mode: local colour, child rays built and traced, nothing stored), go down into the reflection
+ * child if it hit something, then into the transmission child, and on the way up form each node's colour
+ * exactly as fold_values does - local + kr * reflection, then + kt * transmission, then the clamp
+ * (raytrace.c:440-442,547-549,562) - until the subtree's colour goes into the child slot of the level -
+ * 1 node that queued the hit.  No nodes, no queue entries and no folds below `level`.  The pending
+ * ancestors (colour so far, coefficients, the transmission child still to do: its ray, distance and
+ * object, from which the hit point is formed as the spawning lane forms it) wait on a per-lane stack of
+ * RT_DFS_FRAMES frames in scratch memory, touched once per node.  The lanes of a wave run the shade
+ * step together, each on its own node; a lane whose subtree is done waits for the others of its wave.
+ * The host uses this kernel only when the levels are sparse (rt_api.hip) and depth - level < RT_DFS_FRAMES.
+ */
+#define RT_DFS_FRAMES RT_SUBTREE_LEVELS
+template <bool GRID, bool TABLDS, int SHAPE>
+__global__ __launch_bounds__(RT_BLOCK) void k_subtree(DevScene S, DevCamera C, DevWork Wk, uint32_t level)
+{
+    fix_shape<SHAPE>(S);
+    extern __shared__ __attribute__((aligned(16))) float4 lds[];
+    float *lds_park = (float *)lds; /* RT_PARK_FLOATS, ahead of the scene data */
+    float *lds_eye = lds_park;
+    float4 *lds_poly = lds + RT_PARK_FLOATS / 4u;
+    float4 *lds_sph = lds_poly + S.nPolySlots;
+    uint32_t *lds_vis = (uint32_t *)(lds_sph + sphere_slots(S.nSph));
+
+    const uint32_t shard = blockIdx.x % RT_SHARDS;
+    const uint32_t slice = blockIdx.x / RT_SHARDS, nslices = gridDim.x / RT_SHARDS;
+    uint32_t *cnt = Wk.counters;
+    const LevelCounts lc = level_counts(cnt, level, shard);
+    if (overflowed_before(cnt))
+        return; /* the batch is being abandoned: its queues hold unwritten slots */
+    const uint32_t n = min(lc.hits, Wk.capS);
+    if (slice * RT_BLOCK >= n)
+        return; /* block-uniform */
+
+    const Tables<TABLDS> tab = stage_tables<TABLDS>(S, lds_vis);
+    __shared__ float kc[KC_WORDS];
+    stage_colours(S, kc);
+    block_copy(lds_poly, S.poly, S.nPolySlots);
+    if (!GRID) {
+        block_copy(lds_sph, S.sph, S.nSph);
+        for (uint32_t k = threadIdx.x; k < S.nSph; k += RT_BLOCK)
+            ((uint32_t *)(lds_sph + S.nSph))[k] = S.sph_obj[k];
+    }
+    __syncthreads();
+
+    const uint32_t qbase = shard * Wk.capS;
+    const float4 *const inA = Wk.qA(level & 1u);
+    const float4 *const inB = Wk.qB(level & 1u);
+    const float4 *const inC = Wk.qC(level & 1u);
+    SpawnCounts sc;
+    Tally<false> tl;
+    PhaseClock pc;
+    const float bgr = kc[KC_BG + 0], bgg = kc[KC_BG + 1], bgb = kc[KC_BG + 2];
+
+    struct Frame { /* a node whose children are not all known yet */
+        float r, g, b, kr, kt;   /* colour so far, coefficients                                   */
+        uint32_t flags;          /* 1: waiting for the transmission child (else the reflection child);
+                                    2: a transmission child was asked for; 4: ... and it hit: t_*  */
+        float ox, oy, oz, dx, dy, dz, dist;
+        uint32_t obj;
+    };
+    Frame stack[RT_DFS_FRAMES];
+
+    for (uint32_t base = slice * RT_BLOCK; base < n; base += nslices * RT_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        bool active = i < n;
+        const uint32_t at = qbase + min(i, n - 1u);
+        const float4 a = inA[at], b = inB[at], c = inC[at];
+        /* the node being shaded: hit point, object, the ray that found it, its level */
+        float px = a.x, py = a.y, pz = a.z;
+        uint32_t obj = active ? __float_as_uint(a.w) : 0u;
+        const uint32_t parent = active ? __float_as_uint(b.w) : 0u;
+        Ray r;
+        r.ox = b.x; r.oy = b.y; r.oz = b.z;
+        r.dx = c.x; r.dy = c.y; r.dz = c.z;
+        r.mag = 0.0f;
+        uint32_t lv = level, sp = 0;
+        while (__any(active)) {
+            float leaf[3] = {bgr, bgg, bgb};
+            uint32_t node;
+            bool sr, st_;
+            DfsNode nd;
+            StashedEye::park(lds_eye, r);
+            const StashedEye eye_src{lds_eye};
+            const bool inner = shade_and_spawn<GRID, false, TABLDS, false, true>(S, C, Wk, lds_poly, lds_sph, lds_vis, lds_park, kc,
+                                                                                 tab, active, eye_src, px, py, pz, obj, lv, 0u, shard,
+                                                                                 0u, 0u, leaf, node, sr, st_, tl, pc, false, &nd);
+            sc.add(active, sr, st_);
+            if (!active)
+                continue;
+            float vr = leaf[0], vg = leaf[1], vb = leaf[2]; /* colour of a finished subtree, on its way up */
+            bool up = !inner;
+            if (inner) { /* at least one child hit something: this node waits on the stack */
+                Frame f;
+                f.r = nd.r; f.g = nd.g; f.b = nd.b; f.kr = nd.kr; f.kt = nd.kt;
+                f.flags = (nd.want_t ? 2u : 0u) | (nd.hit_t ? 4u : 0u);
+                f.ox = nd.t_ray.ox; f.oy = nd.t_ray.oy; f.oz = nd.t_ray.oz;
+                f.dx = nd.t_ray.dx; f.dy = nd.t_ray.dy; f.dz = nd.t_ray.dz;
+                f.dist = nd.t_dist;
+                f.obj = nd.t_obj;
+                if (nd.hit_r) { /* down into the reflection child: its hit is parked in rows 7-16 */
+                    const float *park = lds_park + threadIdx.x;
+                    px = park[7 * RT_BLOCK]; py = park[8 * RT_BLOCK]; pz = park[9 * RT_BLOCK];
+                    obj = __float_as_uint(park[10 * RT_BLOCK]);
+                    r.ox = park[11 * RT_BLOCK]; r.oy = park[12 * RT_BLOCK]; r.oz = park[13 * RT_BLOCK];
+                    r.dx = park[14 * RT_BLOCK]; r.dy = park[15 * RT_BLOCK]; r.dz = park[16 * RT_BLOCK];
+                } else { /* only the transmission child hit: the reflection ray, if any, left the scene */
+                    if (nd.want_r) { f.r += f.kr * bgr; f.g += f.kr * bgg; f.b += f.kr * bgb; }
+                    f.flags |= 1u;
+                    r = nd.t_ray;
+                    px = r.ox + r.dx * nd.t_dist; py = r.oy + r.dy * nd.t_dist; pz = r.oz + r.dz * nd.t_dist;
+                    obj = nd.t_obj;
+                }
+                stack[sp] = f;
+                ++sp;
+                ++lv;
+            }
+            while (up) { /* a subtree is finished: into its parent, which may finish in turn */
+                if (sp == 0u) {
+                    if ((parent >> 1) < Wk.cap) {
+                        float4 *dst = (parent & 1u) ? Wk.childT() : Wk.childR();
+                        dst[parent >> 1] = make_float4(vr, vg, vb, 0.0f);
+                    }
+                    active = false;
+                    break;
+                }
+                Frame f = stack[sp - 1u];
+                if (!(f.flags & 1u)) { /* it was the reflection child */
+                    f.r += f.kr * vr; f.g += f.kr * vg; f.b += f.kr * vb;
+                    if (f.flags & 4u) { /* now the transmission child: down again */
+                        f.flags |= 1u;
+                        stack[sp - 1u] = f;
+                        r.ox = f.ox; r.oy = f.oy; r.oz = f.oz;
+                        r.dx = f.dx; r.dy = f.dy; r.dz = f.dz;
+                        px = r.ox + r.dx * f.dist; py = r.oy + r.dy * f.dist; pz = r.oz + r.dz * f.dist;
+                        obj = f.obj;
+                        break; /* (lv is this frame's level + 1 already) */
+                    }
+                    if (f.flags & 2u) { f.r += f.kt * bgr; f.g += f.kt * bgg; f.b += f.kt * bgb; }
+                } else { /* it was the transmission child */
+                    f.r += f.kt * vr; f.g += f.kt * vg; f.b += f.kt * vb;
+                }
+                vr = clamp1(f.r); vg = clamp1(f.g); vb = clamp1(f.b);
+                --sp;
+                --lv;
+            }
+        }
+    }
+    uint64_t *st = (uint64_t *)(Wk.counters + CNT_STATS + shard * CNT_STATS_STRIDE);
+    wave_add_total(st, ST_KB_SHADE_NODES, sc.shade_nodes);
+    wave_add_total(st, ST_KB_REFL, sc.refl);
+    wave_add_total(st, ST_KB_TRANS, sc.trans);
+}
+
 #ifndef RT_FAST /* the kernels below do no arithmetic a tolerance could speed up: one copy, shared by both builds */
 /* colour of a tree node once both children are known: raytrace.c:440-442, 547-549, 562 */
 __device__ __forceinline__ uint32_t fold_values(const float4 A, const float2 K, const float4 cr,
@@ -2442,6 +2622,18 @@ void rt_launch_bounce_fast(const DevScene &S, const DevCamera &C, const DevWork 
     const uint32_t grid = queue_grid(Wk, (const void *)kernel, lds, expect);
     kernel<<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, level);
 }
+void rt_launch_subtree_fast(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t level,
+                            uint32_t expect, hipStream_t stream)
+{
+    const size_t lds = rt_scene_lds_bytes(S);
+    const bool grid_scene = S.nSph > RT_TILE_SPHERES;
+    void (*kernel)(DevScene, DevCamera, DevWork, uint32_t) =
+        grid_scene ? k_subtree<true, false, 0>
+        : rt_scene_shape(S) == 1 ? k_subtree<false, true, 1>
+        : S.tabInLds ? k_subtree<false, true, 0> : k_subtree<false, false, 0>;
+    const uint32_t grid = queue_grid(Wk, (const void *)kernel, lds, expect);
+    kernel<<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, level);
+}
 #else
 void rt_launch_bounce(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t level,
                       bool stats, uint32_t expect, hipStream_t stream)
@@ -2453,6 +2645,19 @@ void rt_launch_bounce(const DevScene &S, const DevCamera &C, const DevWork &Wk, 
         : rt_scene_shape(S) == 1 ? (stats ? k_bounce<false, true, true, 1> : k_bounce<false, false, true, 1>)
         : S.tabInLds ? (stats ? k_bounce<false, true, true, 0> : k_bounce<false, false, true, 0>)
                      : (stats ? k_bounce<false, true, false, 0> : k_bounce<false, false, false, 0>);
+    const uint32_t grid = queue_grid(Wk, (const void *)kernel, lds, expect);
+    kernel<<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, level);
+}
+
+void rt_launch_subtree(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t level,
+                       uint32_t expect, hipStream_t stream)
+{
+    const size_t lds = rt_scene_lds_bytes(S);
+    const bool grid_scene = S.nSph > RT_TILE_SPHERES;
+    void (*kernel)(DevScene, DevCamera, DevWork, uint32_t) =
+        grid_scene ? k_subtree<true, false, 0>
+        : rt_scene_shape(S) == 1 ? k_subtree<false, true, 1>
+        : S.tabInLds ? k_subtree<false, true, 0> : k_subtree<false, false, 0>;
     const uint32_t grid = queue_grid(Wk, (const void *)kernel, lds, expect);
     kernel<<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, level);
 }

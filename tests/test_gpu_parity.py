@@ -823,9 +823,11 @@ def test_second_shading_routine_is_bit_identical_and_counts_match(torch_cuda, ma
 @pytest.mark.parametrize("name,W,H,s,d", [("builtin", 640, 480, 2, 8), ("builtin", 333, 217, 3, 16),
                                           ("syn64", 320, 240, 2, 6), ("syn3000", 192, 128, 2, 5)])
 def test_deep_folds_in_one_launch_change_nothing(torch_cuda, make_scene, name, W, H, s, d):
-    """The first render of a frame shape folds every level with a launch of its own; later renders on
-    the same context fold the sparse deep levels in one launch (k_fold_deep).  Same pixels, radiance
-    bits and counters."""
+    """The first render of a frame shape runs and folds every level with a launch of its own; later renders
+    on the same context finish the sparse deep end of the tree in ONE launch, depth first in the lane
+    (k_subtree: no nodes, no queue entries, no folds there), and fold what sparse levels are left above it
+    in one launch (k_fold_deep).  Same pixels, radiance bits and ray counters; what went through HBM
+    (tree_nodes, queued_rays) can only shrink."""
     torch = torch_cuda
     sc = make_scene(name)
     cam = rt.prepare_camera(sc, W, H, s, d)
@@ -837,12 +839,16 @@ def test_deep_folds_in_one_launch_change_nothing(torch_cuda, make_scene, name, W
         rad = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
         ctx.render_rows(cam, argb.data_ptr(), rad.data_ptr())
         st = ctx.finish()
-        outs.append((argb, rad, (st.shade_nodes, st.reflection_rays, st.transmission_rays, st.tree_nodes,
-                                 st.queued_rays, st.overflow_retries)))
+        # (tree_nodes / queued_rays say what went through HBM: fewer once k_subtree takes the deep levels)
+        outs.append((argb, rad, (st.shade_nodes, st.reflection_rays, st.transmission_rays, st.overflow_retries),
+                     (st.tree_nodes, st.queued_rays)))
     for o in outs[1:]:
         assert torch.equal(o[0], outs[0][0])
         assert torch.equal(o[1].view(torch.int32), outs[0][1].view(torch.int32))
         assert o[2] == outs[0][2]
+        assert o[3][0] <= outs[0][3][0] and o[3][1] <= outs[0][3][1]
+    if d >= 5 and name == "builtin":  # (the deep levels of these frames are sparse: the one-launch path did run)
+        assert outs[1][3][1] < outs[0][3][1], [o[3] for o in outs]
     ctx.close()
 
 
@@ -902,7 +908,7 @@ def test_tail_stream_changes_nothing(torch_cuda, make_scene):
         return argb, rad
 
     def counters(st):
-        return (st.shade_nodes, st.reflection_rays, st.transmission_rays, st.tree_nodes, st.queued_rays)
+        return (st.shade_nodes, st.reflection_rays, st.transmission_rays)
 
     a, b = rt.Context(), rt.Context()
     for c in (a, b):
@@ -958,7 +964,7 @@ def test_tail_stream_on_shallow_frames(torch_cuda, make_scene, depth, shading):
         torch.cuda.synchronize()
         ctx.render_rows(cam, argb.data_ptr(), rad.data_ptr(), 0, H, main.cuda_stream)
         st = ctx.finish()
-        outs.append((argb, rad, (st.shade_nodes, st.reflection_rays, st.transmission_rays, st.tree_nodes)))
+        outs.append((argb, rad, (st.shade_nodes, st.reflection_rays, st.transmission_rays)))
     for o in outs[1:]:
         assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1].view(torch.int32), outs[0][1].view(torch.int32))
         assert o[2] == outs[0][2]
@@ -992,7 +998,8 @@ def test_tail_stream_with_small_queues_and_overflow_retries(torch_cuda, make_sce
         st = small.finish()
         retries += st.overflow_retries
         assert st.batches > 1
-        assert (st.shade_nodes, st.tree_nodes, st.queued_rays) == (st0.shade_nodes, st0.tree_nodes, st0.queued_rays)
+        assert (st.shade_nodes, st.reflection_rays, st.transmission_rays) == \
+            (st0.shade_nodes, st0.reflection_rays, st0.transmission_rays)
         assert torch.equal(argb, want) and torch.equal(rad.view(torch.int32), want_rad.view(torch.int32))
     small.close()
 
