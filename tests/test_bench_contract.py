@@ -33,6 +33,9 @@ def test_single_gpu_line_has_the_contract_fields(tail):
     assert d["config"]["workload"].startswith("c2:") and d["config"]["numerics"] == "exact"
     assert 0 < d["config"]["rays_traced_per_step"] < d["config"]["rays_per_step"]   # sky tiles are never generated
     assert d["generic_kernels"]["k_primary_ms"] > d["roofline"]["avg_launch_ms"] * 0.9
+    alone = d["roofline"]["one_frame_at_a_time"]   # the kernel without a neighbour: not slower than beside one
+    assert 0 < alone["k_primary_ms"] <= d["roofline"]["avg_launch_ms"] * 1.1 and 0.05 < alone["frac"] < 1.0
+    assert alone["ms_per_step_one_frame_at_a_time"] > d["ms_per_step"] * 0.9
     assert d["vs_baseline"] is None and d["higher_is_better"] is True
     assert "workload" in d["config"] and "1920x1080" in d["config"]["workload"]
     assert d["config"]["rays_per_step"] == 57693197          # config 2's ray count, equal to the reference's
