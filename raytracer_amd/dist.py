@@ -121,6 +121,8 @@ class FramePipeline:
       done stream:    where the frame is complete (the render stream, or the tail stream of a context)
       comm stream:    wait rendered[k]; all-gather in place; de-interleave into frame; record gathered[k]
     With gather_stream == "same" the comm stream IS the render stream (frames wait for their gathers).
+    render_priority "high": the shared render stream is created with the high stream priority, so that what runs
+    beside it on other streams (a context's tail stream) takes the issue slots it leaves, not its own.
 
     render(i, k, local, stream): enqueue the render of frame i into `local` ([local_rows, width, ...]) on
     `stream` (asynchronous).  finish(i, k): wait for the render, return its statistics (an object with
@@ -130,14 +132,15 @@ class FramePipeline:
     (size the context so that it cannot happen, or gather after collect)."""
 
     def __init__(self, plan, width, dtype, device, rank, render, finish, inflight=2, gather_stream="side",
-                 done_stream=None, collective=True, group=None, render_streams=None, trailing=()):
+                 done_stream=None, collective=True, group=None, render_streams=None, trailing=(),
+                 render_priority="normal"):
         self.plan, self.rank, self.inflight = plan, rank, max(1, inflight)
         self.render_fn, self.finish_fn = render, finish
         self.collective, self.group = collective, group
         self.cuda = torch.device(device).type == "cuda"
         self.gathers = [FrameGather(plan, width, dtype, device, trailing=trailing, rank=rank) for _ in range(self.inflight)]
         if self.cuda:
-            shared = torch.cuda.Stream(device=device)
+            shared = torch.cuda.Stream(device=device, priority=-1 if render_priority == "high" else 0)
             self.streams = list(render_streams) if render_streams else [shared] * self.inflight
             self.comm = (torch.cuda.Stream(device=device) if gather_stream == "side" else None) if plan.world > 1 else None
             self.rendered = [torch.cuda.Event() for _ in range(self.inflight)]
