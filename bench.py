@@ -151,14 +151,14 @@ def main():
                          "grows to N x the pixels")
     ap.add_argument("--sqrt-spp", type=int, default=None)
     ap.add_argument("--depth", type=int, default=None)
-    ap.add_argument("--inflight", type=int, default=2,
-                    help="frames submitted ahead (each with its own render context); they share ONE HIP stream, "
-                         "so kernels of different frames never overlap - only the host's submit/collect latency "
-                         "between frames is hidden")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="frames submitted ahead (each with its own render context) on ONE render stream plus ONE tail "
+                         "stream: three keep the host two frames ahead of the GPU, so that the next k_primary is queued "
+                         "when the render stream falls free (two: 0.2405 ms per frame, three and more: 0.227)")
     ap.add_argument("--render-priority", choices=["high", "normal"], default="high",
                     help="HIP stream priority of the shared render stream (k_primary and the wide bounce levels); the tail "
                          "stream has the normal one.  high: the tail of frame i fills what k_primary of frame i+1 leaves "
-                         "(0.240 ms per frame, k_primary 0.136 ms); normal: the two share alike (0.231 ms, 0.151 ms)")
+                         "(0.227 ms per frame, k_primary 0.125 ms with three frames in flight); normal: the two share alike (0.228 ms, 0.151 ms)")
     ap.add_argument("--overlap", action="store_true",
                     help="give every in-flight frame its own stream (kernels of neighbouring frames overlap; the "
                          "event-timed k_primary duration then includes the sharing and is not a clean roofline input)")
