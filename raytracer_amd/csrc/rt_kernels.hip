@@ -1968,7 +1968,9 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
         Wk.pixAcc[pix] = make_float4(accr, accg, accb, __uint_as_float(nroots));
 
     uint64_t *st = (uint64_t *)(Wk.counters + CNT_STATS + shard * CNT_STATS_STRIDE);
+#ifndef RT_PHASE_NO_K0 /* (development: the phase clocks of the bounce kernels alone) */
     pc.flush(st);
+#endif
     wave_add_total(st, ST_K0_SHADE_NODES, sc.shade_nodes);
     wave_add_total(st, ST_K0_REFL, sc.refl);
     wave_add_total(st, ST_K0_TRANS, sc.trans);

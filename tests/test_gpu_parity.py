@@ -135,6 +135,11 @@ def test_random_scenes_cameras_and_shapes_are_bit_identical():
             differ = (rad.view(np.uint32) != r_o.view(np.uint32)).any(-1)
             assert not differ.any() and np.array_equal(argb, a_o), \
                 f"case {case}: {W}x{H} s{s} d{d} {desc}: {differ.sum()} pixels differ"
+            # once more: the library now knows the frame's level sizes and finishes the sparse deep end of
+            # the tree in one launch, depth first (k_subtree), with the remaining folds merged (k_fold_deep)
+            argb2, rad2 = rt.render(sc, cam)
+            assert np.array_equal(argb2, argb) and np.array_equal(rad2.view(np.uint32), rad.view(np.uint32)), \
+                f"case {case}: {W}x{H} s{s} d{d} {desc}: the second render differs from the first"
     finally:
         O.set_rounded_pow(False)
 
@@ -162,6 +167,9 @@ def test_random_polygon_scene_files_are_bit_identical(tmp_path):
             differ = (rad.view(np.uint32) != r_o.view(np.uint32)).any(-1)
             assert not differ.any() and np.array_equal(argb, a_o), \
                 f"case {case} {W}x{H} s{s} d{d} {kinds}: {differ.sum()} pixels differ\n{text}"
+            argb2, rad2 = rt.render(sc, cam)  # (the second render of a frame: k_subtree, k_fold_deep)
+            assert np.array_equal(argb2, argb) and np.array_equal(rad2.view(np.uint32), rad.view(np.uint32)), \
+                f"case {case} {W}x{H} s{s} d{d} {kinds}: the second render differs from the first\n{text}"
     finally:
         O.set_rounded_pow(False)
 
