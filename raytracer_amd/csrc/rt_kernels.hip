@@ -3,22 +3,29 @@
  * trace-and-shade loop of davidoguns/raytracer (raytrace.c:160-564, 688-790).
  *
  * Pipeline per image batch:
- *   k_primary  : one lane per pixel, loops the sqrtSpp x sqrtSpp sample grid; primary rays are
- *                generated and traced in registers (never touch HBM), depth-0 shade nodes are
- *                lit (shadow rays any-hit inline), childless samples accumulate in registers,
- *                samples that spawn reflection/transmission rays allocate a tree node and push
- *                rays to the level-1 queue with wave ballot / prefix-sum compaction.
- *   k_bounce(d): one lane per queued ray of level d: filtered closest hit, shade, spawn to d+1.
+ *   k_primary  : one lane per pixel (a wave = an 8x8 tile), loops the sqrtSpp x sqrtSpp sample grid.  Tiles
+ *                are classified first from the cones their samples span (sky / no spheres / one polygon /
+ *                every light visible): sky tiles are finished without tracing.  Primary rays are generated
+ *                and traced in registers (never touch HBM), depth-0 shade nodes are lit (shadow rays any-hit
+ *                inline), the child rays are traced by the lane that spawns them; childless samples
+ *                accumulate in registers, samples whose children hit something allocate a tree node and
+ *                queue the HITS for level 1 with wave ballot / prefix-sum compaction.
+ *   k_bounce(d): one lane per queued hit of level d: shade, spawn, trace the children, queue their hits.
+ *   k_subtree(d): the sparse deep end of the tree in one launch: a lane finishes the whole subtree of a
+ *                hit queued for level d, depth first, and writes its colour into the parent's child slot.
  *   k_fold(d)  : deepest level first, node colour = clamp(local + kr*refl + kt*trans) written
  *                into the parent's child slot (the reference clamps at every recursion level,
- *                raytrace.c:562, so the tree cannot be flattened into a throughput product).
- *   k_resolve  : per pixel, fold the depth-0 roots, sum, scale by 1/spp^2, pack ARGB8.
+ *                raytrace.c:562, so the tree cannot be flattened into a throughput product);
+ *                k_fold_deep folds several sparse levels in one launch.
+ *   k_resolve  : per pixel, fold the depth-0 roots, sum in sample order, scale by 1/spp^2, pack ARGB8.
+ *   k_publish  : the batch's counters to the host's mapped mirror, and zeroed.
  *
- * Intersect-all stages the sphere list (cx,cy,cz,r^2) in LDS tiles and every lane of the wave
- * reads the same entry (same-address broadcast, conflict-free); polygon planes, info words and
- * vertices are staged once per block.
+ * Small scenes keep spheres, polygon data and the shading tables in LDS (per-lane indexed reads) and read
+ * what every lane reads from the same address (a search's spheres and planes) through the scalar cache;
+ * big scenes walk a uniform grid in HBM.
  *
- * Numerics: compiled with -ffp-contract=off; every float op is individually rounded in the
+ * Numerics (the exact build; the tolerance build: rt_arith.h): compiled with
+ * -ffp-contract=off; every float op is individually rounded in the
  * order the reference's C expressions evaluate, sqrt/div are IEEE-correct (hipcc default), and
  * the reference's double-precision islands (sphere roots ray.c:217-218, refraction
  * raytrace.c:517-518, angle sum ray.c:98,169) are evaluated in double.  acos is taken in float
