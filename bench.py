@@ -256,6 +256,11 @@ def main():
     del full
     my_rows = sum(n for _, n, _ in plan.rows_of(rank)) if world > 1 else H
 
+    # set-up, before the W warm-up steps: every context renders the frame twice - a context sizes its queues from
+    # its first frame and plans the sparse levels of the tree (k_subtree, k_fold_deep) from the second on
+    for i in range(2 * inflight):
+        pipe.submit(i)
+        pipe.collect(i)
     for i in range(warmup):
         pipe.submit(i)
         pipe.collect(i)
