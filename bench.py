@@ -27,6 +27,11 @@ see nothing and were never generated.  `roofline` prices the dominant kernel (k_
 FLOP constants of SURVEY.md section 8d against the FP32 vector peak: reference-equivalent work / time, NOT a
 utilisation - `roofline.executed_frac` (vector lane operations really issued / what the SIMDs can issue) is
 that.  `cpu_baseline` times the reference (or the oracle port) on the host.
+
+Three frames are in flight (a render context each), on ONE render stream of high priority - k_primary and the wide
+bounce levels, back to back - and ONE tail stream for every frame's sparse deep end (k_subtree), folds, resolve
+and publish, which drain beside the next frame's kernels.  `roofline` times k_primary inside that timed region;
+`roofline.one_frame_at_a_time` is the same kernel with each frame alone on the GPU.
 """
 import argparse
 import json
