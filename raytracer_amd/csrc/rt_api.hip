@@ -218,14 +218,17 @@ uint32_t deep_entries()
 }
 
 /* k_subtree takes the levels that hold at most this many hits per shard (RT_HIP_SUBTREE_MAX in the
- * environment; 0 = never) */
-uint32_t subtree_entries()
+ * environment; 0 = never).  A hit of a scene with a grid costs ten walks through it: there a lane that
+ * finishes a whole subtree alone is the slow way until the levels are nearly empty (config 5's scene at
+ * 1080p, frames pipelined: 59.0 ms with 0 or 64, 60.5 with 512, 61.2 with 4096; its k_subtree took 11.9 ms
+ * where the launches per level it replaced took 8). */
+uint32_t subtree_entries(bool grid)
 {
-    static const uint32_t v = [] {
+    static const long fixed = [] {
         const char *e = getenv("RT_HIP_SUBTREE_MAX");
-        return e && *e ? (uint32_t)strtoul(e, nullptr, 10) : 4096u;
+        return e && *e ? (long)strtoul(e, nullptr, 10) : -1L;
     }();
-    return v;
+    return fixed >= 0 ? (uint32_t)fixed : grid ? 64u : 4096u;
 }
 
 /* enqueue one image batch */
@@ -274,11 +277,12 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
      * hit (k_subtree): no launch per level, no nodes and no folds there.  The first render of a shape, the
      * instrumented kernels and trees deeper than the kernel's stack take one launch per level. */
     uint32_t sub = depth + 1u; /* first level k_subtree takes (depth + 1: none) */
-    if (c->seen_valid && !stats && c->shading == RT_SHADE_PHONG && subtree_entries() != 0u) {
+    const uint32_t sub_max = subtree_entries(c->S.grid != nullptr);
+    if (c->seen_valid && !stats && c->shading == RT_SHADE_PHONG && sub_max != 0u) {
         uint32_t l = depth;
-        while (l > 2u && c->seen_hits[l - 1u] <= subtree_entries() && depth - (l - 1u) < RT_SUBTREE_LEVELS)
+        while (l > 2u && c->seen_hits[l - 1u] <= sub_max && depth - (l - 1u) < RT_SUBTREE_LEVELS)
             --l;
-        if (l < depth && c->seen_hits[l] <= subtree_entries() && depth - l < RT_SUBTREE_LEVELS)
+        if (l < depth && c->seen_hits[l] <= sub_max && depth - l < RT_SUBTREE_LEVELS)
             sub = l;
     }
     bool moved = false;

@@ -76,7 +76,16 @@ struct PhaseClock {
 
 /* -DRT_TILE_CLOCKS (tools/tile_probe.py): waves and wave cycles of k_primary per class of tile, in the
  * statistic slots the plain build leaves unused (ST_SPH_TESTS + 2 * class: waves, + 1: cycles). */
-#ifdef RT_TILE_CLOCKS
+#ifdef RT_TILE_TRACE /* (tools/tile_trace.py: start / end of every k_primary wave on the 100 MHz wall clock) */
+static __device__ unsigned long long rt_tile_trace[65536 * 4];
+#define RT_DEV_TILE_START() const unsigned long long tile_t0_ = wall_clock64()
+#define RT_DEV_TILE_END(st, cls) do { if (__lane_id() == 0) { \
+    const unsigned w_ = (blockIdx.y * gridDim.x + blockIdx.x) * 4u + (threadIdx.x >> 6); \
+    if (w_ < 65536u) { rt_tile_trace[w_ * 4u] = tile_t0_; rt_tile_trace[w_ * 4u + 1u] = wall_clock64(); \
+        rt_tile_trace[w_ * 4u + 2u] = (cls); \
+        rt_tile_trace[w_ * 4u + 3u] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) /* HW_ID */ \
+            | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32); } } } while (0)
+#elif defined(RT_TILE_CLOCKS)
 #define RT_DEV_TILE_START() const unsigned long long tile_t0_ = clock64()
 #define RT_DEV_TILE_END(st, cls) do { if (__lane_id() == 0) { \
     atomicAdd((unsigned long long *)&(st)[ST_SPH_TESTS + 2 * (cls)], 1ull); \

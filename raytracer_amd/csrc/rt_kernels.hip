@@ -2738,3 +2738,10 @@ void rt_launch_publish(uint32_t *counters, uint32_t *mirror, uint32_t words, hip
     k_publish<<<(n16 + RT_BLOCK - 1) / RT_BLOCK, RT_BLOCK, 0, stream>>>((uint4 *)counters, (uint4 *)mirror, n16);
 }
 #endif /* RT_FAST */
+
+#if defined(RT_TILE_TRACE) && defined(RT_FAST)
+extern "C" int rt_dev_tile_trace_read(void *host, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(rt_tile_trace), bytes);
+}
+#endif
