@@ -270,7 +270,7 @@ def main():
         pipe.submit(i)
         pipe.collect(i)
     for c in ctxs:
-        c.set_timing(True)
+        c.set_timing(not os.environ.get("RT_BENCH_NO_K0_EVENTS"))  # (development: the run without the events)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()

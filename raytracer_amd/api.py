@@ -173,6 +173,10 @@ class Context:
         fused multiply-adds, 1-ulp rcp / rsq / sqrt) - rt_hip_ctx_set_numerics"""
         check(load().rt_hip_ctx_set_numerics(self._h, int(mode)), "rt_hip_ctx_set_numerics")
 
+    def set_launch_plan(self, on):
+        """False: k_primary's blocks always in raster order (rt_hip_ctx_set_launch_plan)"""
+        load().rt_hip_ctx_set_launch_plan(self._h, int(bool(on)))
+
     def set_specialization(self, on):
         """False: generic kernels also for the reference's scene shape (rt_hip_ctx_set_specialization)"""
         load().rt_hip_ctx_set_specialization(self._h, int(bool(on)))

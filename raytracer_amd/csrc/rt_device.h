@@ -101,6 +101,13 @@ enum {
  *   y_limit = H, out_first = 8*t0 (rows of the rank's compact local buffer)               */
 struct DevRows {
     uint32_t y_first, y_step, y_limit, out_first, ntiles;
+    /* k_primary's launch order (rt_api.hip, "launch plan"): block b of the grid, counted row by row, renders
+     * block column plan[b] & 0xffff of tile row plan[b] >> 16 - a permutation of the raster, so any plan
+     * renders the same frame.  nullptr: the raster itself, top-down. */
+    const uint32_t *plan = nullptr;
+    /* where every wave of k_primary leaves the time it took, in 10 ns ticks of the wall clock:
+     * wave_ticks[(tile row * block columns + block column) * 4 + wave]; nullptr: not recorded */
+    uint32_t *wave_ticks = nullptr;
 };
 
 /* Per-batch work state in HBM. */

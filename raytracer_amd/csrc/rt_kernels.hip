@@ -127,6 +127,11 @@ __device__ __forceinline__ float4 const_load4(const float4 *p)
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
+__device__ __forceinline__ uint32_t const_load1(const uint32_t *p)
+{
+    return *((const __attribute__((address_space(4))) uint32_t *)(uintptr_t)p);
+}
+
 __device__ __forceinline__ float mag3(float x, float y, float z)
 {
     return sqrt_rn((x * x + y * y) + z * z);
@@ -1788,8 +1793,21 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
     RT_DEV_TILE_START();
     /* a wave owns an 8x8 pixel tile; the block is 4 tiles side by side (32x8 pixels) */
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t x = blockIdx.x * 32u + wv * 8u + (lane & 7u);
-    const uint32_t ty = blockIdx.y; /* (tile rows top-down: every other order measured slower, profiles/r02_pmc_notes.md) */
+    /* Which block of the batch this is: the raster top-down, or - once the context has timed a frame of this
+     * shape - the launch plan's order, slowest blocks first (rt_api.hip: the launch is as long as the waves
+     * that start last and run longest; the raster started the floor's edge and shadow tiles at 80 us of 122). */
+    uint32_t bx = blockIdx.x, ty = blockIdx.y;
+    if (R.plan) {
+        const uint32_t e = const_load1(R.plan + (blockIdx.y * gridDim.x + blockIdx.x));
+        bx = e & 0xffffu;
+        ty = e >> 16;
+    }
+    const unsigned long long wave_t0 = R.wave_ticks ? wall_clock64() : 0ull;
+    auto wave_done = [&]() { /* (every exit of the kernel) */
+        if (R.wave_ticks && lane == 0u)
+            R.wave_ticks[(ty * gridDim.x + bx) * (RT_BLOCK / 64u) + wv] = (uint32_t)(wall_clock64() - wave_t0);
+    };
+    const uint32_t x = bx * 32u + wv * 8u + (lane & 7u);
     const uint32_t y = R.y_first + ty * R.y_step + (lane >> 3);
     const bool valid = (x < C.W) && (y < R.y_limit);
 
@@ -1798,7 +1816,7 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
     const float fv0 = ((C.hfbH - (float)y) / C.hfbH) * C.halfH;
 
     /* every wave feeds its own shard: even a single tile row spreads over all of them */
-    const uint32_t shard = ((ty * gridDim.x + blockIdx.x) * (RT_BLOCK / 64u) +
+    const uint32_t shard = ((ty * gridDim.x + bx) * (RT_BLOCK / 64u) +
                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) % RT_SHARDS;
     const uint32_t node_base = shard * Wk.capS; /* level 0 opens every shard's node range */
 
@@ -1846,6 +1864,7 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
                 Wk.pixAcc[pix] = make_float4(accr, accg, accb, __uint_as_float(0u));
             wave_add_total(stats, ST_K0_CULLED, (uint32_t)__popcll(__ballot(valid)) * C.sqrtSpp * C.sqrtSpp);
             RT_DEV_TILE_END(stats, 0);
+            wave_done();
             return true;
         }
 #ifdef RT_FAST
@@ -1861,6 +1880,7 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
                         Wk.pixAcc[pix] = make_float4(accr, accg, accb, __uint_as_float(0u));
                     wave_add_total(stats, ST_K0_SHADE_NODES, (uint32_t)__popcll(__ballot(valid)) * C.sqrtSpp * C.sqrtSpp);
                     RT_DEV_TILE_END(stats, 1);
+                    wave_done();
                     return true;
                 }
             }
@@ -1983,6 +2003,7 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
     wave_add_total(st, ST_K0_TRANS, sc.trans);
     flush_tally<STATS>(st, tl, true);
     RT_DEV_TILE_END(st, tile_polygon != RT_NONE ? 2 : tile_no_spheres ? 3 : 4);
+    wave_done();
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -2162,6 +2183,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_subtree(DevScene S, DevCamera C, D
     Tally<false> tl;
     PhaseClock pc;
     const float bgr = kc[KC_BG + 0], bgg = kc[KC_BG + 1], bgb = kc[KC_BG + 2];
+    /* colour += k * child, a product and a sum each rounded - what k_fold does (fold_values, compiled once without
+     * contraction for both builds): a frame of the tolerance build must not depend on which of the two folded it */
+    auto fold_child = [](auto &f, float k, float cr_, float cg_, float cb_) {
+        f.r = __fadd_rn(f.r, __fmul_rn(k, cr_));
+        f.g = __fadd_rn(f.g, __fmul_rn(k, cg_));
+        f.b = __fadd_rn(f.b, __fmul_rn(k, cb_));
+    };
 
     struct Frame { /* a node whose children are not all known yet */
         float r, g, b, kr, kt;   /* colour so far, coefficients                                   */
@@ -2216,7 +2244,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_subtree(DevScene S, DevCamera C, D
                     r.ox = park[11 * RT_BLOCK]; r.oy = park[12 * RT_BLOCK]; r.oz = park[13 * RT_BLOCK];
                     r.dx = park[14 * RT_BLOCK]; r.dy = park[15 * RT_BLOCK]; r.dz = park[16 * RT_BLOCK];
                 } else { /* only the transmission child hit: the reflection ray, if any, left the scene */
-                    if (nd.want_r) { f.r += f.kr * bgr; f.g += f.kr * bgg; f.b += f.kr * bgb; }
+                    if (nd.want_r) fold_child(f, f.kr, bgr, bgg, bgb);
                     f.flags |= 1u;
                     r = nd.t_ray;
                     px = r.ox + r.dx * nd.t_dist; py = r.oy + r.dy * nd.t_dist; pz = r.oz + r.dz * nd.t_dist;
@@ -2237,7 +2265,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_subtree(DevScene S, DevCamera C, D
                 }
                 Frame f = stack[sp - 1u];
                 if (!(f.flags & 1u)) { /* it was the reflection child */
-                    f.r += f.kr * vr; f.g += f.kr * vg; f.b += f.kr * vb;
+                    fold_child(f, f.kr, vr, vg, vb);
                     if (f.flags & 4u) { /* now the transmission child: down again */
                         f.flags |= 1u;
                         stack[sp - 1u] = f;
@@ -2247,9 +2275,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_subtree(DevScene S, DevCamera C, D
                         obj = f.obj;
                         break; /* (lv is this frame's level + 1 already) */
                     }
-                    if (f.flags & 2u) { f.r += f.kt * bgr; f.g += f.kt * bgg; f.b += f.kt * bgb; }
+                    if (f.flags & 2u) fold_child(f, f.kt, bgr, bgg, bgb);
                 } else { /* it was the transmission child */
-                    f.r += f.kt * vr; f.g += f.kt * vg; f.b += f.kt * vb;
+                    fold_child(f, f.kt, vr, vg, vb);
                 }
                 vr = clamp1(f.r); vg = clamp1(f.g); vb = clamp1(f.b);
                 --sp;
