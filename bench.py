@@ -159,11 +159,15 @@ def main():
     ap.add_argument("--inflight", type=int, default=3,
                     help="frames submitted ahead (each with its own render context) on ONE render stream plus ONE tail "
                          "stream: three keep the host two frames ahead of the GPU, so that the next k_primary is queued "
-                         "when the render stream falls free (two: 0.2405 ms per frame, three and more: 0.227)")
+                         "when the render stream falls free (two: 0.228 ms per frame, three: 0.225, four: 0.220)")
     ap.add_argument("--render-priority", choices=["high", "normal"], default="high",
                     help="HIP stream priority of the shared render stream (k_primary and the wide bounce levels); the tail "
                          "stream has the normal one.  high: the tail of frame i fills what k_primary of frame i+1 leaves "
-                         "(0.227 ms per frame, k_primary 0.125 ms with three frames in flight); normal: the two share alike (0.228 ms, 0.151 ms)")
+                         "(0.225 ms per frame, k_primary 0.114 ms with three frames in flight); normal: the two share alike (0.212 ms, 0.124 ms)")
+    ap.add_argument("--launch-plan", choices=["on", "off"], default="on",
+                    help="k_primary's launch plan (rt_hip_ctx_set_launch_plan): each context times the tiles of its first "
+                         "frame and launches the blocks of the next ones slowest first; off: raster order, top-down "
+                         "(k_primary alone 0.099 against 0.124 ms, 0.114 against 0.125 ms in the pipelined run)")
     ap.add_argument("--overlap", action="store_true",
                     help="give every in-flight frame its own stream (kernels of neighbouring frames overlap; the "
                          "event-timed k_primary duration then includes the sharing and is not a clean roofline input)")
@@ -227,6 +231,7 @@ def main():
         c = rt.Context(device=local_rank)  # queue capacity sized by the first render of this rank's share
         c.upload(scene)
         c.set_numerics(numerics)
+        c.set_launch_plan(args.launch_plan == "on")
         if tail is not None:
             c.set_tail_stream(tail.cuda_stream)
         ctxs.append(c)
@@ -262,7 +267,8 @@ def main():
     my_rows = sum(n for _, n, _ in plan.rows_of(rank)) if world > 1 else H
 
     # set-up, before the W warm-up steps: every context renders the frame twice - a context sizes its queues from
-    # its first frame and plans the sparse levels of the tree (k_subtree, k_fold_deep) from the second on
+    # its first frame, times its tiles for k_primary's launch plan, and plans the sparse levels of the tree
+    # (k_subtree, k_fold_deep) from the second on
     for i in range(2 * inflight):
         pipe.submit(i)
         pipe.collect(i)
@@ -347,6 +353,7 @@ def main():
                        "frames_in_flight": inflight,
                        "streams": "one per frame" if args.overlap else ("shared + tail stream" if tail is not None else "shared"),
                        "render_stream_priority": args.render_priority,
+                       "k_primary_launch_plan": args.launch_plan,
                        "parallelism": "1 GPU" if world == 1 else f"cyclic 8-row blocks over {world} GPUs"},
             "roofline": {"bound": "fp32_valu", "kernel": "k_primary", "achieved": achieved,
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,

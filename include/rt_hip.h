@@ -206,7 +206,9 @@ typedef struct rt_hip_ctx rt_hip_ctx;
 /* Create a render context on HIP device `device` (-1 = current).  max_queue_rays = capacity
  * of each per-level ray queue and of the node pool, 152 bytes per entry.  0 = sized by the renders: the
  * first render allocates one entry per primary sample of its job (at least 1 Mi, at most
- * RT_HIP_QUEUE_CAP from the environment, else 64 Mi entries = 9.5 GiB), a later, larger job re-allocates;
+ * RT_HIP_QUEUE_CAP from the environment, else 256 Mi entries = 38 GiB of the GPU's 288: a 3840x2160 frame of
+ * 4x4 samples is ONE batch of 19 GiB, which k_primary's launch plan needs and which pays the latency of the
+ * tree's sparse deep levels once - 0.987 -> 0.853 ms for BASELINE config 3), a later, larger job re-allocates;
  * jobs beyond the capacity are rendered in row batches. */
 int  rt_hip_ctx_create(rt_hip_ctx **out, int device, uint64_t max_queue_rays);
 void rt_hip_ctx_destroy(rt_hip_ctx *ctx);

@@ -32,6 +32,7 @@ thread_local char g_err[512] = "";
 
 constexpr uint32_t kMaxBatches = 64;            /* counter slots per enqueue round */
 constexpr uint64_t kDefaultCap = 64ull << 20;   /* entries per queue / node pool   */
+constexpr uint64_t kAutoCapLimit = 256ull << 20; /* ... of a context that sizes itself (38 GiB of the 288) */
 
 /* a run of 8-row tile rows [t0,t1) of the current job, rendered as one image batch */
 struct Batch {
@@ -747,7 +748,7 @@ int rt_hip_ctx_create(rt_hip_ctx **out, int device, uint64_t max_queue_rays)
         const char *env = getenv("RT_HIP_QUEUE_CAP");
         cap = env ? strtoull(env, nullptr, 0) : 0;
         c->auto_cap = true;
-        c->cap_limit = round_cap(cap ? cap : kDefaultCap);
+        c->cap_limit = round_cap(cap ? cap : kAutoCapLimit);
         cap = 0;
     } else {
         cap = round_cap(cap);

@@ -2,7 +2,7 @@
 Per build ("c2:fast", "c2:exact") and kernel: per-launch averages over the timed launches of each pass."""
 import collections, csv, glob, json, re, sys
 tag = sys.argv[1]
-out = {"_comment": "rocprofv3 --pmc, one run per pass (tools/final_profile_r02.sh), bench.py --steps 2 --tail-stream off at "
+out = {"_comment": "rocprofv3 --pmc, one run per pass (tools/final_profile_r02.sh), bench.py --steps 10 --tail-stream off at "
                    "config 2 (builtin scene 1920x1080, 4x4 samples, depth 8), per-launch averages. SQ_* summed over the chip; "
                    "SQ_BUSY_CYCLES / 32 = elapsed shader cycles; SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* in quad-cycles. "
                    "FETCH_SIZE / WRITE_SIZE in KiB; hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: gfx950 tallies "
