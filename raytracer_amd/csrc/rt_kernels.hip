@@ -2376,16 +2376,26 @@ __global__ __launch_bounds__(RT_BLOCK * RT_DEEP_SUB) void k_fold_deep(DevWork Wk
 
 /* k_resolve: per pixel - fold this pixel's depth-0 roots, add them to the in-register sum of
  * the childless samples, scale (raytrace.c:779), store radiance, pack (raytrace.c:783-790). */
+#ifndef RT_RESOLVE_GRID
+#define RT_RESOLVE_GRID 4096u
+#endif
 __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DevCamera C, DevWork Wk, DevRows R,
                                                       uint32_t *argb, float *radiance)
 {
     if (overflowed_before(Wk.counters))
         return; /* rows of an abandoned batch are rendered again by the host in smaller batches */
     const size_t npix = (size_t)R.ntiles * 8u * C.W;
-    for (size_t p = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x; p < npix; p += (size_t)gridDim.x * RT_BLOCK) {
-        const uint32_t row = (uint32_t)(p / C.W); /* row of the batch: tile row*8 + line */
-        if (R.y_first + (row >> 3) * R.y_step + (row & 7u) >= R.y_limit)
+    /* A wave takes the 8x8 pixel tile a wave of k_primary rendered, a block the same 32x8 pixels: the nodes of
+     * the tile's k-th roots were reserved together and lie side by side, so a wave's 64 gathers per root are
+     * whole lines that no other wave touches (pixel rows across the grid read every line of node data from up
+     * to eight blocks, on as many XCDs). */
+    const uint32_t nbx = (C.W + 31u) / 32u, lane = threadIdx.x & 63u;
+    for (uint32_t blk = blockIdx.x; blk < nbx * R.ntiles; blk += gridDim.x) {
+        const uint32_t x = (blk % nbx) * 32u + (threadIdx.x >> 6) * 8u + (lane & 7u);
+        const uint32_t row = (blk / nbx) * 8u + (lane >> 3); /* row of the batch: tile row*8 + line */
+        if (x >= C.W || R.y_first + (row >> 3) * R.y_step + (row & 7u) >= R.y_limit)
             continue; /* the last tile row of a slab may hang over its end */
+        const size_t p = (size_t)row * C.W + x;
         const float4 acc = Wk.pixAcc[p];
         float r = acc.x, g = acc.y, b = acc.z;
         const uint32_t nroots = __float_as_uint(acc.w);
@@ -2713,10 +2723,9 @@ void rt_launch_fold(const DevWork &Wk, uint32_t level, uint32_t expect, hipStrea
 void rt_launch_resolve(const DevCamera &C, const DevWork &Wk, const DevRows &R, uint32_t *d_argb,
                        float *d_radiance, hipStream_t stream)
 {
-    const size_t npix = (size_t)R.ntiles * 8u * C.W;
-    size_t grid = (npix + RT_BLOCK - 1) / RT_BLOCK;
-    if (grid > 4096)
-        grid = 4096;
+    size_t grid = (size_t)((C.W + 31u) / 32u) * R.ntiles; /* blocks of 32x8 pixels, as k_primary's */
+    if (grid > RT_RESOLVE_GRID)
+        grid = RT_RESOLVE_GRID;
     if (grid == 0)
         grid = 1;
     k_resolve<<<(uint32_t)grid, RT_BLOCK, 0, stream>>>(C, Wk, R, d_argb, d_radiance);
