@@ -115,9 +115,11 @@ struct DevWork {
     /* Ten arrays of `cap` entries in one allocation, `stride` bytes apart, addressed from ONE base
      * pointer: thirteen pointers as kernel arguments kept ~26 scalar registers live through the
      * trace kernels, which spilled them into VGPR lanes (300 v_readlane / v_writelane in k_primary).
-     *   slot 3p+0  qA[p]  hit queue of level parity p: (hit point, bits object)
-     *   slot 3p+1  qB[p]  (origin of the ray that found the hit, bits parent<<1|slot)
-     *   slot 3p+2  qC[p]  (direction of that ray, -)
+     *   slot 3p+0  qA[p]  hit queue of level parity p: (origin of the ray that found the hit, distance along it)
+     *   slot 3p+1  qB[p]  (direction of that ray, bits parent<<1|slot)
+     *   slot 3p+2  qObj[p] object hit, 4 bytes an entry (the rest of the slot is unused): 36 bytes a hit - the
+     *                     consumer forms the hit point as the producer would (hit_point, rt_kernels.hip); with
+     *                     the point stored too an entry was 48 bytes, 28 MB more written and read per frame
      *   slot 6     nodeA  (local rgb, kr)                 written when the node is made
      *   slot 7     childR (reflection child rgb, -)       written by the child, as a whole float4:
      *   slot 8     childT (transmission child rgb, -)     consecutive rays have consecutive parents,
@@ -137,7 +139,7 @@ struct DevWork {
     __host__ __device__ __forceinline__ float4 *slot(uint32_t k) const { return (float4 *)(base + (uint64_t)k * stride); }
     __host__ __device__ __forceinline__ float4 *qA(uint32_t parity) const { return slot(3u * parity + 0u); }
     __host__ __device__ __forceinline__ float4 *qB(uint32_t parity) const { return slot(3u * parity + 1u); }
-    __host__ __device__ __forceinline__ float4 *qC(uint32_t parity) const { return slot(3u * parity + 2u); }
+    __host__ __device__ __forceinline__ uint32_t *qObj(uint32_t parity) const { return (uint32_t *)slot(3u * parity + 2u); }
     __host__ __device__ __forceinline__ float4 *nodeA() const { return slot(6u); }
     __host__ __device__ __forceinline__ float4 *childR() const { return slot(7u); }
     __host__ __device__ __forceinline__ float4 *childT() const { return slot(8u); }

@@ -132,6 +132,16 @@ __device__ __forceinline__ uint32_t const_load1(const uint32_t *p)
     return *((const __attribute__((address_space(4))) uint32_t *)(uintptr_t)p);
 }
 
+/* where a ray meets what it hit, d along it: origin + direction * d, a product and a sum each rounded (ray.c:121-122,
+ * 236-237) in BOTH builds - the hit queues carry (ray, distance), and every kernel that takes a hit from them, or
+ * goes down into a child itself, must form the same point */
+__device__ __forceinline__ void hit_point(const Ray &r, float d, float &px, float &py, float &pz)
+{
+    px = __fadd_rn(r.ox, __fmul_rn(r.dx, d));
+    py = __fadd_rn(r.oy, __fmul_rn(r.dy, d));
+    pz = __fadd_rn(r.oz, __fmul_rn(r.dz, d));
+}
+
 __device__ __forceinline__ float mag3(float x, float y, float z)
 {
     return sqrt_rn((x * x + y * y) + z * z);
@@ -1325,10 +1335,9 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
         const bool chit = want && (cobj != RT_NONE);
         if (child == 0u) {
             hit_r = chit;
-            /* the child's hit point, as its get_ray_color would form it (ray.c:121-122, 236-237) */
-            park[7 * RT_BLOCK] = cr.ox + cr.dx * cd;
-            park[8 * RT_BLOCK] = cr.oy + cr.dy * cd;
-            park[9 * RT_BLOCK] = cr.oz + cr.dz * cd;
+            /* the child's hit: distance and object (the hit point is formed from the ray where it is needed,
+             * hit_point() below, as the child's get_ray_color would form it: ray.c:121-122, 236-237) */
+            park[7 * RT_BLOCK] = cd;
             park[10 * RT_BLOCK] = __uint_as_float(cobj);
             park[11 * RT_BLOCK] = cr.ox; park[12 * RT_BLOCK] = cr.oy; park[13 * RT_BLOCK] = cr.oz;
             park[14 * RT_BLOCK] = cr.dx; park[15 * RT_BLOCK] = cr.dy; park[16 * RT_BLOCK] = cr.dz;
@@ -1397,20 +1406,19 @@ __device__ __forceinline__ bool shade_and_spawn(const DevScene &S, const DevCame
     const uint32_t odd_next = (level + 1) & 1u;
     float4 *const outA = Wk.qA(odd_next);
     float4 *const outB = Wk.qB(odd_next);
-    float4 *const outC = Wk.qC(odd_next);
+    uint32_t *const outO = Wk.qObj(odd_next);
     const uint32_t qbase = shard * Wk.capS;
-    if (slot_r != RT_NONE) {
-        outA[qbase + slot_r] = make_float4(park[7 * RT_BLOCK], park[8 * RT_BLOCK], park[9 * RT_BLOCK],
-                                           park[10 * RT_BLOCK]);
-        outB[qbase + slot_r] = make_float4(park[11 * RT_BLOCK], park[12 * RT_BLOCK], park[13 * RT_BLOCK],
+    if (slot_r != RT_NONE) { /* 36 bytes a hit: (ray origin, distance), (ray direction, parent), object */
+        outA[qbase + slot_r] = make_float4(park[11 * RT_BLOCK], park[12 * RT_BLOCK], park[13 * RT_BLOCK],
+                                           park[7 * RT_BLOCK]);
+        outB[qbase + slot_r] = make_float4(park[14 * RT_BLOCK], park[15 * RT_BLOCK], park[16 * RT_BLOCK],
                                            __uint_as_float((node << 1) | 0u));
-        outC[qbase + slot_r] = make_float4(park[14 * RT_BLOCK], park[15 * RT_BLOCK], park[16 * RT_BLOCK], 0.f);
+        outO[qbase + slot_r] = __float_as_uint(park[10 * RT_BLOCK]);
     }
     if (slot_t != RT_NONE) {
-        outA[qbase + slot_t] = make_float4(cr.ox + cr.dx * cd, cr.oy + cr.dy * cd, cr.oz + cr.dz * cd,
-                                           __uint_as_float(cobj));
-        outB[qbase + slot_t] = make_float4(cr.ox, cr.oy, cr.oz, __uint_as_float((node << 1) | 1u));
-        outC[qbase + slot_t] = make_float4(cr.dx, cr.dy, cr.dz, 0.f);
+        outA[qbase + slot_t] = make_float4(cr.ox, cr.oy, cr.oz, cd);
+        outB[qbase + slot_t] = make_float4(cr.dx, cr.dy, cr.dz, __uint_as_float((node << 1) | 1u));
+        outO[qbase + slot_t] = cobj;
     }
     pc.mark(6);
     return true;
@@ -2061,39 +2069,42 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_BOUNCE1 : RT_WPE)) v
      */
     const float4 *const inA = Wk.qA(level & 1u);
     const float4 *const inB = Wk.qB(level & 1u);
-    const float4 *const inC = Wk.qC(level & 1u);
+    const uint32_t *const inO = Wk.qObj(level & 1u);
     /* (loads are unconditional, on an index clamped into the shard's entries: a load under a branch
      * makes the compiler merge old and new values and wait right behind the load) */
-    float4 na, nb, nc;
+    float4 na, nb;
+    uint32_t nc;
     {
         const uint32_t first = min(slice * RT_BLOCK + threadIdx.x, n - 1u);
         na = inA[qbase + first];
         nb = inB[qbase + first];
-        nc = inC[qbase + first];
+        nc = inO[qbase + first];
     }
 #define RT_LANDED(P_, Q_, R_) \
     asm volatile("" : "+v"(P_.x), "+v"(P_.y), "+v"(P_.z), "+v"(P_.w), "+v"(Q_.x), "+v"(Q_.y), "+v"(Q_.z), \
-                      "+v"(Q_.w), "+v"(R_.x), "+v"(R_.y), "+v"(R_.z))
+                      "+v"(Q_.w), "+v"(R_))
     RT_LANDED(na, nb, nc);
     for (uint32_t base = slice * RT_BLOCK; base < n; base += nslices * RT_BLOCK) {
         const uint32_t i = base + threadIdx.x;
         const bool active = i < n;
         pc.start();
-        const float4 a = na, b = nb, c = nc;
+        const float4 a = na, b = nb;
+        const uint32_t c = nc;
         {
             const uint32_t inext = min(i + nslices * RT_BLOCK, n - 1u);
             na = inA[qbase + inext];
             nb = inB[qbase + inext];
-            nc = inC[qbase + inext];
+            nc = inO[qbase + inext];
         }
-        /* a queued hit: (point, object), (origin of the ray that found it, parent), (its direction) */
-        const float px = a.x, py = a.y, pz = a.z;
-        const uint32_t obj = active ? __float_as_uint(a.w) : 0u;
-        const uint32_t parent = active ? __float_as_uint(b.w) : 0u;
+        /* a queued hit: (origin of the ray that found it, distance), (its direction, parent), object */
         Ray r;
-        r.ox = b.x; r.oy = b.y; r.oz = b.z;
-        r.dx = c.x; r.dy = c.y; r.dz = c.z;
+        r.ox = a.x; r.oy = a.y; r.oz = a.z;
+        r.dx = b.x; r.dy = b.y; r.dz = b.z;
         r.mag = 0.0f;
+        float px, py, pz;
+        hit_point(r, a.w, px, py, pz);
+        const uint32_t obj = active ? c : 0u;
+        const uint32_t parent = active ? __float_as_uint(b.w) : 0u;
         pc.mark(0);
         pc.mark(1);
         const bool hit = active;
@@ -2178,7 +2189,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_subtree(DevScene S, DevCamera C, D
     const uint32_t qbase = shard * Wk.capS;
     const float4 *const inA = Wk.qA(level & 1u);
     const float4 *const inB = Wk.qB(level & 1u);
-    const float4 *const inC = Wk.qC(level & 1u);
+    const uint32_t *const inO = Wk.qObj(level & 1u);
     SpawnCounts sc;
     Tally<false> tl;
     PhaseClock pc;
@@ -2204,15 +2215,16 @@ __global__ __launch_bounds__(RT_BLOCK) void k_subtree(DevScene S, DevCamera C, D
         const uint32_t i = base + threadIdx.x;
         bool active = i < n;
         const uint32_t at = qbase + min(i, n - 1u);
-        const float4 a = inA[at], b = inB[at], c = inC[at];
+        const float4 a = inA[at], b = inB[at];
         /* the node being shaded: hit point, object, the ray that found it, its level */
-        float px = a.x, py = a.y, pz = a.z;
-        uint32_t obj = active ? __float_as_uint(a.w) : 0u;
+        uint32_t obj = active ? inO[at] : 0u;
         const uint32_t parent = active ? __float_as_uint(b.w) : 0u;
         Ray r;
-        r.ox = b.x; r.oy = b.y; r.oz = b.z;
-        r.dx = c.x; r.dy = c.y; r.dz = c.z;
+        r.ox = a.x; r.oy = a.y; r.oz = a.z;
+        r.dx = b.x; r.dy = b.y; r.dz = b.z;
         r.mag = 0.0f;
+        float px, py, pz;
+        hit_point(r, a.w, px, py, pz);
         uint32_t lv = level, sp = 0;
         while (__any(active)) {
             float leaf[3] = {bgr, bgg, bgb};
@@ -2239,15 +2251,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_subtree(DevScene S, DevCamera C, D
                 f.obj = nd.t_obj;
                 if (nd.hit_r) { /* down into the reflection child: its hit is parked in rows 7-16 */
                     const float *park = lds_park + threadIdx.x;
-                    px = park[7 * RT_BLOCK]; py = park[8 * RT_BLOCK]; pz = park[9 * RT_BLOCK];
                     obj = __float_as_uint(park[10 * RT_BLOCK]);
                     r.ox = park[11 * RT_BLOCK]; r.oy = park[12 * RT_BLOCK]; r.oz = park[13 * RT_BLOCK];
                     r.dx = park[14 * RT_BLOCK]; r.dy = park[15 * RT_BLOCK]; r.dz = park[16 * RT_BLOCK];
+                    hit_point(r, park[7 * RT_BLOCK], px, py, pz);
                 } else { /* only the transmission child hit: the reflection ray, if any, left the scene */
                     if (nd.want_r) fold_child(f, f.kr, bgr, bgg, bgb);
                     f.flags |= 1u;
                     r = nd.t_ray;
-                    px = r.ox + r.dx * nd.t_dist; py = r.oy + r.dy * nd.t_dist; pz = r.oz + r.dz * nd.t_dist;
+                    hit_point(r, nd.t_dist, px, py, pz);
                     obj = nd.t_obj;
                 }
                 stack[sp] = f;
@@ -2271,7 +2283,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_subtree(DevScene S, DevCamera C, D
                         stack[sp - 1u] = f;
                         r.ox = f.ox; r.oy = f.oy; r.oz = f.oz;
                         r.dx = f.dx; r.dy = f.dy; r.dz = f.dz;
-                        px = r.ox + r.dx * f.dist; py = r.oy + r.dy * f.dist; pz = r.oz + r.dz * f.dist;
+                        hit_point(r, f.dist, px, py, pz);
                         obj = f.obj;
                         break; /* (lv is this frame's level + 1 already) */
                     }
