@@ -73,7 +73,8 @@ struct rt_hip_ctx {
     void *work_blob = nullptr;
     DevWork W{};
     float4 *pixAcc = nullptr;
-    size_t pix_cap = 0;
+    uint8_t *tile_done = nullptr; /* one flag per 8x8 tile of a batch (DevRows::tile_done), allocated with pixAcc */
+    size_t pix_cap = 0, tile_cap = 0;
     uint32_t *roots = nullptr; /* [spp^2][pixels of a batch] */
     size_t roots_cap = 0;
     uint32_t *d_counters = nullptr; /* [kMaxBatches][RT_COUNTER_WORDS] */
@@ -183,6 +184,16 @@ int ensure_pix(rt_hip_ctx *c, size_t npix, size_t spp2)
         HIP_TRY(hipMalloc((void **)&c->pixAcc, npix * sizeof(float4)));
         c->pix_cap = npix;
     }
+    /* one flag per tile: the batch's tile rows x ceil(W / 32) blocks x 4 tiles */
+    const size_t tiles = c->C.W ? npix / (8u * (size_t)c->C.W) * ((c->C.W + 31u) / 32u) * (RT_BLOCK / 64u) : 0;
+    if (tiles > c->tile_cap) {
+        if (c->tile_done)
+            HIP_TRY(hipFree(c->tile_done));
+        c->tile_done = nullptr;
+        c->tile_cap = 0;
+        HIP_TRY(hipMalloc((void **)&c->tile_done, tiles));
+        c->tile_cap = tiles;
+    }
     if (npix * spp2 > c->roots_cap) {
         if (c->roots)
             HIP_TRY(hipFree(c->roots));
@@ -209,6 +220,9 @@ DevRows rows_of(const rt_hip_ctx *c, const Batch &b)
         R.y_step = 8u;
         R.y_limit = j.row0 + j.nrows;
     }
+    R.argb = c->d_argb;
+    R.radiance = c->d_rad;
+    R.tile_done = c->tile_done;
     if (b.t0 == 0 && b.t1 == j.ntiles) { /* the whole job in one batch: what a launch plan is for */
         if (c->plan_use)
             R.plan = c->d_plan;
@@ -800,6 +814,7 @@ void rt_hip_ctx_destroy(rt_hip_ctx *c)
     if (c->scene_blob) (void)hipFree(c->scene_blob);
     if (c->work_blob) (void)hipFree(c->work_blob);
     if (c->pixAcc) (void)hipFree(c->pixAcc);
+    if (c->tile_done) (void)hipFree(c->tile_done);
     if (c->roots) (void)hipFree(c->roots);
     if (c->d_plan) (void)hipFree(c->d_plan);
     if (c->d_wave_ticks) (void)hipFree(c->d_wave_ticks);

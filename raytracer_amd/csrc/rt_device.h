@@ -108,6 +108,13 @@ struct DevRows {
     /* where every wave of k_primary leaves the time it took, in 10 ns ticks of the wall clock:
      * wave_ticks[(tile row * block columns + block column) * 4 + wave]; nullptr: not recorded */
     uint32_t *wave_ticks = nullptr;
+    /* Pixels of tiles none of whose samples became a root (sky, plain floor: 85 % of the tiles of the reference's
+     * scene) are finished by k_primary itself - scaled, packed and stored to the frame (argb, radiance or nullptr),
+     * tile_done[(tile row * block columns + block column) * 4 + wave] = 1 - and k_resolve skips them: their 16
+     * bytes of pixel sums are neither written nor read back.  Every wave of k_primary writes its flag. */
+    uint32_t *argb = nullptr;
+    float *radiance = nullptr;
+    uint8_t *tile_done = nullptr;
 };
 
 /* Per-batch work state in HBM. */

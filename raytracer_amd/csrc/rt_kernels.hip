@@ -1790,6 +1790,23 @@ template <> __device__ __forceinline__ void fix_shape<1>(DevScene &S)
     S.nSph = 2u; S.nPoly = 1u; S.nPolySlots = 10u; S.nObj = 3u; S.nLights = 1u; S.tabSlots = 17u;
 }
 
+/* a pixel's sum of sample colours -> the frame: x 1/spp^2 (raytrace.c:779), radiance, 8-bit pack (raytrace.c:783-790).
+ * p: pixel of the batch.  k_resolve's last step, and k_primary's for the tiles without roots. */
+__device__ __forceinline__ void store_pixel(const DevCamera &C, const DevRows &R, size_t p, float r, float g, float b,
+                                            uint32_t *argb, float *radiance)
+{
+    r = r * C.scale; g = g * C.scale; b = b * C.scale;
+    const size_t o = (size_t)R.out_first * C.W + p;
+    if (radiance) {
+        radiance[3 * o + 0] = r; radiance[3 * o + 1] = g; radiance[3 * o + 2] = b;
+    }
+    /* (unsigned char)(255 * c): truncation, low byte of the int conversion */
+    const uint32_t R8 = (uint32_t)(int)(255.0f * r) & 0xFFu;
+    const uint32_t G8 = (uint32_t)(int)(255.0f * g) & 0xFFu;
+    const uint32_t B8 = (uint32_t)(int)(255.0f * b) & 0xFFu;
+    argb[o] = 0xFF000000u | (R8 << 16) | (G8 << 8) | B8;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* k_primary: get_pixel_color + get_ray_color + depth-0 get_shade_color_phong, fused           */
 /* ------------------------------------------------------------------------------------------ */
@@ -1814,6 +1831,12 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
     auto wave_done = [&]() { /* (every exit of the kernel) */
         if (R.wave_ticks && lane == 0u)
             R.wave_ticks[(ty * gridDim.x + bx) * (RT_BLOCK / 64u) + wv] = (uint32_t)(wall_clock64() - wave_t0);
+    };
+    /* the wave's tile has no roots: its pixels are final (wave-uniform; DevRows::tile_done) */
+    auto tile_is_final = [&](bool final) {
+        if (R.tile_done && lane == 0u)
+            R.tile_done[(ty * gridDim.x + bx) * (RT_BLOCK / 64u) + wv] = final ? 1u : 0u;
+        return final && R.tile_done != nullptr;
     };
     const uint32_t x = bx * 32u + wv * 8u + (lane & 7u);
     const uint32_t y = R.y_first + ty * R.y_step + (lane >> 3);
@@ -1868,8 +1891,12 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
                 accg = accg + src.kc(KC_BG + 1);
                 accb = accb + src.kc(KC_BG + 2);
             }
-            if (valid)
+            if (tile_is_final(true)) {
+                if (valid)
+                    store_pixel(C, R, pix, accr, accg, accb, R.argb, R.radiance);
+            } else if (valid) {
                 Wk.pixAcc[pix] = make_float4(accr, accg, accb, __uint_as_float(0u));
+            }
             wave_add_total(stats, ST_K0_CULLED, (uint32_t)__popcll(__ballot(valid)) * C.sqrtSpp * C.sqrtSpp);
             RT_DEV_TILE_END(stats, 0);
             wave_done();
@@ -1884,8 +1911,12 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
                 const bool spawns = __builtin_amdgcn_readfirstlane((int)((mC.z != 0.0f || mC.w != 0.0f) && C.depth != 0u)) != 0;
                 if (!spawns) { /* raytrace.c:405,452 */
                     lit_polygon_tile(S, C, src, tile_polygon, prec, fu0, fv0, accr, accg, accb);
-                    if (valid)
+                    if (tile_is_final(true)) {
+                        if (valid)
+                            store_pixel(C, R, pix, accr, accg, accb, R.argb, R.radiance);
+                    } else if (valid) {
                         Wk.pixAcc[pix] = make_float4(accr, accg, accb, __uint_as_float(0u));
+                    }
                     wave_add_total(stats, ST_K0_SHADE_NODES, (uint32_t)__popcll(__ballot(valid)) * C.sqrtSpp * C.sqrtSpp);
                     RT_DEV_TILE_END(stats, 1);
                     wave_done();
@@ -1999,8 +2030,12 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
             pc.mark(7);
         }
     }
-    if (valid)
+    if (tile_is_final(__all(!valid || nroots == 0u))) {
+        if (valid)
+            store_pixel(C, R, pix, accr, accg, accb, R.argb, R.radiance);
+    } else if (valid) {
         Wk.pixAcc[pix] = make_float4(accr, accg, accb, __uint_as_float(nroots));
+    }
 
     uint64_t *st = (uint64_t *)(Wk.counters + CNT_STATS + shard * CNT_STATS_STRIDE);
 #ifndef RT_PHASE_NO_K0 /* (development: the phase clocks of the bounce kernels alone) */
@@ -2403,6 +2438,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DevCamera C, DevWork Wk, D
      * to eight blocks, on as many XCDs). */
     const uint32_t nbx = (C.W + 31u) / 32u, lane = threadIdx.x & 63u;
     for (uint32_t blk = blockIdx.x; blk < nbx * R.ntiles; blk += gridDim.x) {
+        if (R.tile_done && R.tile_done[blk * (RT_BLOCK / 64u) + (threadIdx.x >> 6)])
+            continue; /* (wave-uniform) k_primary has finished this tile's pixels */
         const uint32_t x = (blk % nbx) * 32u + (threadIdx.x >> 6) * 8u + (lane & 7u);
         const uint32_t row = (blk / nbx) * 8u + (lane >> 3); /* row of the batch: tile row*8 + line */
         if (x >= C.W || R.y_first + (row >> 3) * R.y_step + (row & 7u) >= R.y_limit)
@@ -2439,16 +2476,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DevCamera C, DevWork Wk, D
                 }
             }
         }
-        r = r * C.scale; g = g * C.scale; b = b * C.scale;
-        const size_t o = (size_t)R.out_first * C.W + p;
-        if (radiance) {
-            radiance[3 * o + 0] = r; radiance[3 * o + 1] = g; radiance[3 * o + 2] = b;
-        }
-        /* (unsigned char)(255 * c): truncation, low byte of the int conversion */
-        const uint32_t R = (uint32_t)(int)(255.0f * r) & 0xFFu;
-        const uint32_t G = (uint32_t)(int)(255.0f * g) & 0xFFu;
-        const uint32_t Bl = (uint32_t)(int)(255.0f * b) & 0xFFu;
-        argb[o] = 0xFF000000u | (R << 16) | (G << 8) | Bl;
+        store_pixel(C, R, p, r, g, b, argb, radiance);
     }
 }
 
