@@ -346,6 +346,12 @@ void rt_hip_ctx_set_specialization(rt_hip_ctx *ctx, int enable);
  * No counterpart in the reference (its pixels are one serial loop, raytrace.c:746-792). */
 void rt_hip_ctx_set_launch_plan(rt_hip_ctx *ctx, int enable);
 
+/* The host half of the launch plan, exported for tests (no GPU involved): the order rt_hip_finish builds from
+ * wave_ticks[(tile row * block_columns + block column) * 4 + wave], the time each of a block's four waves took -
+ * blocks by their slowest wave, slowest first, equal times in raster order.  plan[i] = block column | tile row << 16,
+ * block_columns * tile_rows entries.  No counterpart in the reference. */
+void rt_launch_plan_order(const uint32_t *wave_ticks, uint32_t block_columns, uint32_t tile_rows, uint32_t *plan);
+
 /* Bracket the fused primary kernel with HIP events on the render stream (k0_ms). */
 void rt_hip_ctx_set_timing(rt_hip_ctx *ctx, int enable);
 /* Cap on primary samples per image batch (0 = automatic). */

@@ -498,8 +498,8 @@ int enqueue_round(rt_hip_ctx *c)
     return 0;
 }
 
-/* The frame's single batch recorded its waves' times: order the blocks slowest first (stable: equal times
- * stay in raster order) and put the order where k_primary reads it.  Blocking; once per view. */
+/* The frame's single batch recorded its waves' times: order the blocks slowest first and put the order where
+ * k_primary reads it.  Blocking; once per view. */
 int rebuild_plan(rt_hip_ctx *c)
 {
     const uint32_t nbx = (c->C.W + 31u) / 32u, ntiles = c->job.ntiles;
@@ -507,26 +507,8 @@ int rebuild_plan(rt_hip_ctx *c)
     std::vector<uint32_t> ticks(blocks * (RT_BLOCK / 64u));
     HIP_TRY(hipMemcpyAsync(ticks.data(), c->d_wave_ticks, ticks.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    std::vector<uint32_t> cost(blocks);
-    uint32_t most = 0;
-    for (size_t b = 0; b < blocks; ++b) { /* a block is as slow as its slowest wave */
-        uint32_t t = 0;
-        for (uint32_t w = 0; w < RT_BLOCK / 64u; ++w)
-            t = ticks[b * (RT_BLOCK / 64u) + w] > t ? ticks[b * (RT_BLOCK / 64u) + w] : t;
-        cost[b] = t;
-        most = t > most ? t : most;
-    }
-    uint32_t shift = 0; /* counting sort on at most 2^16 keys */
-    while ((most >> shift) >= (1u << 16))
-        ++shift;
-    std::vector<uint32_t> start((1u << 16) + 1u, 0u);
-    for (size_t b = 0; b < blocks; ++b)
-        start[0xffffu - (cost[b] >> shift) + 1u]++;
-    for (size_t k = 1; k < start.size(); ++k)
-        start[k] += start[k - 1];
     std::vector<uint32_t> plan(blocks);
-    for (size_t b = 0; b < blocks; ++b)
-        plan[start[0xffffu - (cost[b] >> shift)]++] = (uint32_t)(b % nbx) | ((uint32_t)(b / nbx) << 16);
+    rt_launch_plan_order(ticks.data(), nbx, ntiles, plan.data());
     HIP_TRY(hipMemcpyAsync(c->d_plan, plan.data(), blocks * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream)); /* (plan[] is this function's) */
     c->plan_valid = true;
@@ -698,6 +680,35 @@ void drop_events(rt_hip_ctx *c)
 } // namespace
 
 extern "C" {
+
+/* k_primary's launch order from the times its waves took (wave_ticks[(tile row * nbx + block column) * 4 + wave]):
+ * the blocks slowest first - a block is as slow as its slowest wave - equal times in raster order (a stable counting
+ * sort on at most 2^16 keys: times beyond that lose their low bits).  plan[i] = block column | tile row << 16. */
+void rt_launch_plan_order(const uint32_t *wave_ticks, uint32_t nbx, uint32_t ntiles, uint32_t *plan)
+{
+    const size_t blocks = (size_t)nbx * ntiles;
+    constexpr uint32_t waves = RT_BLOCK / 64u;
+    std::vector<uint32_t> cost(blocks);
+    uint32_t most = 0;
+    for (size_t b = 0; b < blocks; ++b) {
+        uint32_t t = 0;
+        for (uint32_t w = 0; w < waves; ++w)
+            t = wave_ticks[b * waves + w] > t ? wave_ticks[b * waves + w] : t;
+        cost[b] = t;
+        most = t > most ? t : most;
+    }
+    uint32_t shift = 0;
+    while ((most >> shift) >= (1u << 16))
+        ++shift;
+    std::vector<uint32_t> start((1u << 16) + 1u, 0u);
+    for (size_t b = 0; b < blocks; ++b)
+        start[0xffffu - (cost[b] >> shift) + 1u]++;
+    for (size_t k = 1; k < start.size(); ++k)
+        start[k] += start[k - 1];
+    for (size_t b = 0; b < blocks; ++b)
+        plan[start[0xffffu - (cost[b] >> shift)]++] = (uint32_t)(b % nbx) | ((uint32_t)(b / nbx) << 16);
+}
+
 
 const char *rt_hip_last_error(void) { return g_err; }
 const char *rt_hip_version(void) { return "rt_hip 0.1 (gfx950)"; }

@@ -277,3 +277,28 @@ def test_scene_loader_under_sanitizers_on_mutated_files():
                        text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "300 files, 0 batches with findings" in p.stdout
+
+
+def test_launch_plan_order_is_a_stable_sort_slowest_first():
+    """rt_launch_plan_order (the host half of k_primary's launch plan): every block once, by its slowest wave,
+    slowest first, ties in raster order; times beyond 16 bits are compared by their high bits."""
+    import numpy as np
+    from raytracer_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(7)
+    for nbx, nty, hi in [(1, 1, 10), (7, 5, 50), (60, 135, 12000), (3, 4, 1 << 30), (120, 270, 3)]:
+        ticks = rng.integers(0, hi, size=(nty * nbx, 4), dtype=np.uint32)
+        ticks[rng.integers(0, nty * nbx, size=max(1, nty * nbx // 3))] = 0  # sky tiles: many ties
+        plan = np.zeros(nty * nbx, dtype=np.uint32)
+        lib.rt_launch_plan_order(ticks.ctypes.data, nbx, nty, plan.ctypes.data)
+        bx, ty = plan & 0xFFFF, plan >> 16
+        assert (bx < nbx).all() and (ty < nty).all()
+        blk = ty.astype(np.int64) * nbx + bx
+        assert np.array_equal(np.sort(blk), np.arange(nty * nbx))  # a permutation of the raster
+        cost = ticks.max(axis=1).astype(np.int64)
+        shift = 0
+        while (int(cost.max()) >> shift) >= 1 << 16:
+            shift += 1
+        key = cost >> shift
+        want = np.lexsort((np.arange(nty * nbx), -key))  # by key descending, then raster order
+        assert np.array_equal(blk, want)
