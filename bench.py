@@ -164,10 +164,12 @@ def main():
                     help="HIP stream priority of the shared render stream (k_primary and the wide bounce levels); the tail "
                          "stream has the normal one.  high: the tail of frame i fills what k_primary of frame i+1 leaves "
                          "(0.225 ms per frame, k_primary 0.114 ms with three frames in flight); normal: the two share alike (0.212 ms, 0.124 ms)")
-    ap.add_argument("--launch-plan", choices=["on", "off"], default="on",
+    ap.add_argument("--launch-plan", choices=["on", "off", "pairs"], default="on",
                     help="k_primary's launch plan (rt_hip_ctx_set_launch_plan): each context times the tiles of its first "
                          "frame and launches the blocks of the next ones slowest first; off: raster order, top-down "
-                         "(k_primary alone 0.099 against 0.124 ms, 0.114 against 0.125 ms in the pipelined run)")
+                         "(k_primary alone 0.099 against 0.124 ms, 0.106 against 0.125 ms in the pipelined run); pairs: and the slow "
+                         "blocks of launches that do not fill the GPU as pairs (mode 2: a rank's eighth of config 3, "
+                         "k_primary 0.062 against 0.094 ms, but the frame loop there is bound by the host: 0.166 against 0.153 ms)")
     ap.add_argument("--overlap", action="store_true",
                     help="give every in-flight frame its own stream (kernels of neighbouring frames overlap; the "
                          "event-timed k_primary duration then includes the sharing and is not a clean roofline input)")
@@ -231,7 +233,7 @@ def main():
         c = rt.Context(device=local_rank)  # queue capacity sized by the first render of this rank's share
         c.upload(scene)
         c.set_numerics(numerics)
-        c.set_launch_plan(args.launch_plan == "on")
+        c.set_launch_plan({"off": 0, "on": 1, "pairs": 2}[args.launch_plan])
         if tail is not None:
             c.set_tail_stream(tail.cuda_stream)
         ctxs.append(c)
@@ -290,12 +292,19 @@ def main():
         acc["shadow"] += st.shadow_rays
         acc["culled"] += st.primary_rays_culled
 
+    host = [0.0, 0.0]  # (development, RT_BENCH_HOST_TIMES=1: seconds the host spent in collect / in submit)
     for i in range(steps):
+        ta = time.perf_counter()
         if i >= inflight:
             tally(pipe.collect(i - inflight))
+        tb = time.perf_counter()
         pipe.submit(i)
+        host[0] += tb - ta
+        host[1] += time.perf_counter() - tb
     for i in range(max(0, steps - inflight), steps):
         tally(pipe.collect(i))
+    if os.environ.get("RT_BENCH_HOST_TIMES"):
+        print("host per frame: collect %.1f us, submit %.1f us" % (host[0] / steps * 1e6, host[1] / steps * 1e6), file=sys.stderr)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

@@ -157,6 +157,8 @@ typedef struct {
     /* k_primary launches of this render that followed a launch plan, and plans built at its end
      * (rt_hip_ctx_set_launch_plan) */
     uint32_t planned_launches, plan_builds;
+    uint32_t plan_pairs;        /* blocks the plan built at the end of this render launches as pairs */
+    uint32_t reserved_;
 } rt_hip_stats;
 
 /* ------------------------------------------------------------------------------------ */
@@ -336,20 +338,26 @@ int  rt_hip_ctx_set_tail_stream(rt_hip_ctx *ctx, void *stream);
  * No counterpart in the reference. */
 void rt_hip_ctx_set_specialization(rt_hip_ctx *ctx, int enable);
 
-/* Launch plan of the fused primary kernel (on by default; enable = 0 launches the raster top-down, always).
- * A render that fits one image batch records how long every 8x8-pixel tile took; the next renders of
- * the same frame shape on this context launch the 32x8-pixel blocks slowest first, so that the kernel does
- * not end on tiles that start late and run long (reference scene, 1080p 16 spp: 0.124 -> 0.104 ms).  The plan
- * is a permutation of the blocks - pixels and ray counters do not depend on it - built once per view
- * (camera, rows, scene) at the end of the recording render (rt_hip_finish: one 4-byte-per-wave copy to the
- * host, a counting sort, one copy back) and refreshed every 8th render while the view keeps changing.
+/* Launch plan of the fused primary kernel.  mode 0: the raster top-down, always.  mode 1 (the default): a render that
+ * fits one image batch records how long every 8x8-pixel tile took; the next renders of the same frame shape on
+ * this context launch the 32x8-pixel blocks slowest first, so that the kernel does not end on tiles that start
+ * late and run long (reference scene, 1080p 16 spp: 0.124 -> 0.099 ms).  The plan is a permutation of the blocks -
+ * pixels and ray counters do not depend on it - built once per view (camera, rows, scene) at the end of the
+ * recording render (rt_hip_finish: one 4-byte-per-wave copy to the host, a counting sort, one copy back) and
+ * refreshed every 8th render while the view keeps changing.
+ * mode 2: as 1, and a launch whose slow tiles (over 20 us) leave half of the GPU's wave slots free - it is as long
+ * as its slowest tile whatever the order - lists the blocks of those tiles TWICE: the two blocks share the samples
+ * of the tiles (the second block's finished samples wait as colours beside the pixel's root ids and are added in
+ * the reference's order by the resolve kernel: same pixels).  A rank's eighth of a 4K frame: 0.094 -> 0.062 ms for
+ * the kernel; worth it where the launch's latency counts (one small frame at a time), not in a frame loop that is
+ * bound by the host.  mode 3: every block a pair (tests).
  * No counterpart in the reference (its pixels are one serial loop, raytrace.c:746-792). */
-void rt_hip_ctx_set_launch_plan(rt_hip_ctx *ctx, int enable);
+void rt_hip_ctx_set_launch_plan(rt_hip_ctx *ctx, int mode);
 
 /* The host half of the launch plan, exported for tests (no GPU involved): the order rt_hip_finish builds from
  * wave_ticks[(tile row * block_columns + block column) * 4 + wave], the time each of a block's four waves took -
- * blocks by their slowest wave, slowest first, equal times in raster order.  plan[i] = block column | tile row << 16,
- * block_columns * tile_rows entries.  No counterpart in the reference. */
+ * blocks by their slowest wave, slowest first, equal times in raster order.  plan[i] = block column | tile row << 15,
+ * block_columns * tile_rows entries (both below 32768).  No counterpart in the reference. */
 void rt_launch_plan_order(const uint32_t *wave_ticks, uint32_t block_columns, uint32_t tile_rows, uint32_t *plan);
 
 /* Bracket the fused primary kernel with HIP events on the render stream (k0_ms). */

@@ -174,8 +174,9 @@ class Context:
         check(load().rt_hip_ctx_set_numerics(self._h, int(mode)), "rt_hip_ctx_set_numerics")
 
     def set_launch_plan(self, on):
-        """False: k_primary's blocks always in raster order (rt_hip_ctx_set_launch_plan)"""
-        load().rt_hip_ctx_set_launch_plan(self._h, int(bool(on)))
+        """False / 0: k_primary's blocks always in raster order; True / 1 (the default): slowest first; 2: ... and the
+        slow blocks of small launches as pairs; 3: every block a pair (tests) (rt_hip_ctx_set_launch_plan)"""
+        load().rt_hip_ctx_set_launch_plan(self._h, int(on))
 
     def set_specialization(self, on):
         """False: generic kernels also for the reference's scene shape (rt_hip_ctx_set_specialization)"""

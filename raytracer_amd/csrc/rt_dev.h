@@ -80,7 +80,7 @@ struct PhaseClock {
 static __device__ unsigned long long rt_tile_trace[65536 * 4];
 #define RT_DEV_TILE_START() const unsigned long long tile_t0_ = wall_clock64()
 #define RT_DEV_TILE_END(st, cls) do { if (__lane_id() == 0) { \
-    const unsigned w_ = (ty * gridDim.x + bx) * 4u + (threadIdx.x >> 6); \
+    const unsigned w_ = (ty * nbx + bx) * 4u + (threadIdx.x >> 6); \
     if (w_ < 65536u) { rt_tile_trace[w_ * 4u] = tile_t0_; rt_tile_trace[w_ * 4u + 1u] = wall_clock64(); \
         rt_tile_trace[w_ * 4u + 2u] = (cls); \
         rt_tile_trace[w_ * 4u + 3u] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) /* HW_ID */ \

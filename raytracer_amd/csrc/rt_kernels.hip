@@ -1821,21 +1821,28 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
     /* Which block of the batch this is: the raster top-down, or - once the context has timed a frame of this
      * shape - the launch plan's order, slowest blocks first (rt_api.hip: the launch is as long as the waves
      * that start last and run longest; the raster started the floor's edge and shadow tiles at 80 us of 122). */
-    uint32_t bx = blockIdx.x, ty = blockIdx.y;
-    if (R.plan) {
-        const uint32_t e = const_load1(R.plan + (blockIdx.y * gridDim.x + blockIdx.x));
-        bx = e & 0xffffu;
-        ty = e >> 16;
+    /* A plan may list a block TWICE, side by side (a pair: RT_PLAN_PAIRED, second copy RT_PLAN_SECOND): the two
+     * blocks share every tile's sample rows - where the whole launch is no longer than its longest wave (a rank's
+     * share of a frame spread over eight GPUs: 4 000 blocks, the tiles of the glass sphere 90 us each). */
+    uint32_t bx = blockIdx.x, ty = blockIdx.y, half = 0;
+    bool paired = false;
+    const uint32_t nbx = (C.W + 31u) / 32u;
+    if (R.plan) { /* (a 1-D grid of plan_len blocks) */
+        const uint32_t e = const_load1(R.plan + blockIdx.x);
+        bx = e & 0x7fffu;
+        ty = (e >> 15) & 0x7fffu;
+        paired = (e & RT_PLAN_PAIRED) != 0u;
+        half = e >> 31;
     }
     const unsigned long long wave_t0 = R.wave_ticks ? wall_clock64() : 0ull;
-    auto wave_done = [&]() { /* (every exit of the kernel) */
-        if (R.wave_ticks && lane == 0u)
-            R.wave_ticks[(ty * gridDim.x + bx) * (RT_BLOCK / 64u) + wv] = (uint32_t)(wall_clock64() - wave_t0);
+    auto wave_done = [&]() { /* (every exit of the kernel; of a pair the first block's waves: the host doubles them) */
+        if (R.wave_ticks && lane == 0u && half == 0u)
+            R.wave_ticks[(ty * nbx + bx) * (RT_BLOCK / 64u) + wv] = (uint32_t)(wall_clock64() - wave_t0);
     };
-    /* the wave's tile has no roots: its pixels are final (wave-uniform; DevRows::tile_done) */
+    /* the wave's tile has no roots: its pixels are final (wave-uniform; DevRows::tile_done; first block of a pair only) */
     auto tile_is_final = [&](bool final) {
         if (R.tile_done && lane == 0u)
-            R.tile_done[(ty * gridDim.x + bx) * (RT_BLOCK / 64u) + wv] = final ? 1u : 0u;
+            R.tile_done[(ty * nbx + bx) * (RT_BLOCK / 64u) + wv] = final ? 1u : 0u;
         return final && R.tile_done != nullptr;
     };
     const uint32_t x = bx * 32u + wv * 8u + (lane & 7u);
@@ -1847,7 +1854,7 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
     const float fv0 = ((C.hfbH - (float)y) / C.hfbH) * C.halfH;
 
     /* every wave feeds its own shard: even a single tile row spreads over all of them */
-    const uint32_t shard = ((ty * gridDim.x + bx) * (RT_BLOCK / 64u) +
+    const uint32_t shard = ((ty * nbx + bx) * (RT_BLOCK / 64u) + half * 2u +
                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) % RT_SHARDS;
     const uint32_t node_base = shard * Wk.capS; /* level 0 opens every shard's node range */
 
@@ -1886,6 +1893,8 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
         }
         uint64_t *const stats = (uint64_t *)(Wk.counters + CNT_STATS + shard * CNT_STATS_STRIDE);
         if (__all(nothing)) { /* wave-uniform */
+            if (half != 0u)
+                return true; /* the first block of the pair finishes such a tile */
             for (uint32_t k = 0; k < C.sqrtSpp * C.sqrtSpp; ++k) {
                 accr = accr + src.kc(KC_BG + 0);
                 accg = accg + src.kc(KC_BG + 1);
@@ -1910,6 +1919,8 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
                 const float4 mC = src.tab(prec + RT_OBJ_PHONG);
                 const bool spawns = __builtin_amdgcn_readfirstlane((int)((mC.z != 0.0f || mC.w != 0.0f) && C.depth != 0u)) != 0;
                 if (!spawns) { /* raytrace.c:405,452 */
+                    if (half != 0u)
+                        return true;
                     lit_polygon_tile(S, C, src, tile_polygon, prec, fu0, fv0, accr, accg, accb);
                     if (tile_is_final(true)) {
                         if (valid)
@@ -1967,7 +1978,17 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
             return; /* wave-uniform; no barrier follows */
     }
 
-    for (uint32_t j = 0; j < C.sqrtSpp; ++j) {
+    /* A tile launched as a pair and not finished above: the first wave takes the first half of the sample rows,
+     * the second the rest - as roots all of them, from slot (sqrtSpp / 2) * sqrtSpp on: it cannot know what the
+     * first wave's samples became, and k_resolve adds a pixel's samples in the reference's order (raytrace.c:774),
+     * the first wave's sum and roots, then these.  An odd number of sample rows: the first wave takes them all. */
+    const bool split = paired && (C.sqrtSpp & 1u) == 0u;
+    if (half != 0u && !split)
+        return;
+    const uint32_t j_first = split && half ? C.sqrtSpp / 2u : 0u, j_end = split && !half ? C.sqrtSpp / 2u : C.sqrtSpp;
+    if (split && half)
+        nroots = (C.sqrtSpp / 2u) * C.sqrtSpp;
+    for (uint32_t j = j_first; j < j_end; ++j) {
         for (uint32_t i = 0; i < C.sqrtSpp; ++i) {
             float px, py, pz;
             uint32_t obj;
@@ -2009,14 +2030,24 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
              * not commute: a finished sample that FOLLOWS a root of its pixel must be added after
              * that root, so it becomes a childless root itself (silhouette pixels only: rare). */
             if (valid && !deferred && nroots != 0u) {
-                uint32_t local, no_r, no_t;
-                wave_reserve(level_line(Wk.counters, 0u, shard), false, false, Wk.capS, Wk.capS,
-                             &Wk.counters[CNT_OVERFLOW], local, no_r, no_t);
-                if (local != RT_NONE) {
-                    node = node_base + local;
-                    Wk.nodeA()[node] = make_float4(leaf[0], leaf[1], leaf[2], 0.0f);
-                    Wk.nodeK()[node] = make_float2(0.0f, __uint_as_float(RT_LINK_NONE << 3));
+                if (split && half && R.leaf2) {
+                    /* the second wave of a pair, whose samples are all roots: the finished ones leave their colour
+                     * beside the root ids (a coalesced 16-byte store; a node costs a reservation, 24 bytes here
+                     * and a 56-byte gather in k_resolve - with nodes the pairs cost k_resolve what they saved here) */
+                    R.leaf2[(size_t)(nroots - (C.sqrtSpp / 2u) * C.sqrtSpp) * pix_stride + pix] =
+                        make_float4(leaf[0], leaf[1], leaf[2], 0.0f);
+                    node = RT_LEAF_ROOT;
                     deferred = true;
+                } else {
+                    uint32_t local, no_r, no_t;
+                    wave_reserve(level_line(Wk.counters, 0u, shard), false, false, Wk.capS, Wk.capS,
+                                 &Wk.counters[CNT_OVERFLOW], local, no_r, no_t);
+                    if (local != RT_NONE) {
+                        node = node_base + local;
+                        Wk.nodeA()[node] = make_float4(leaf[0], leaf[1], leaf[2], 0.0f);
+                        Wk.nodeK()[node] = make_float2(0.0f, __uint_as_float(RT_LINK_NONE << 3));
+                        deferred = true;
+                    }
                 }
             }
             if (deferred) {
@@ -2030,11 +2061,13 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
             pc.mark(7);
         }
     }
-    if (tile_is_final(__all(!valid || nroots == 0u))) {
+    if (split && half) {
+        /* (the second wave of a pair leaves roots only) */
+    } else if (tile_is_final(!split && __all(!valid || nroots == 0u))) {
         if (valid)
             store_pixel(C, R, pix, accr, accg, accb, R.argb, R.radiance);
     } else if (valid) {
-        Wk.pixAcc[pix] = make_float4(accr, accg, accb, __uint_as_float(nroots));
+        Wk.pixAcc[pix] = make_float4(accr, accg, accb, __uint_as_float(nroots | (split ? RT_ROOTS_SPLIT : 0u)));
     }
 
     uint64_t *st = (uint64_t *)(Wk.counters + CNT_STATS + shard * CNT_STATS_STRIDE);
@@ -2426,6 +2459,10 @@ __global__ __launch_bounds__(RT_BLOCK * RT_DEEP_SUB) void k_fold_deep(DevWork Wk
 #ifndef RT_RESOLVE_GRID
 #define RT_RESOLVE_GRID 4096u
 #endif
+/* PAIRS: the launch plan of this batch has pairs (DevRows::plan): pixels of shared tiles have their roots in two
+ * runs, the second possibly with finished colours in place of nodes.  A kernel of its own: that path costs 32
+ * registers, and the plain kernel, which every other frame runs, would pay for them with a third of its waves. */
+template <bool PAIRS>
 __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DevCamera C, DevWork Wk, DevRows R,
                                                       uint32_t *argb, float *radiance)
 {
@@ -2447,14 +2484,22 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DevCamera C, DevWork Wk, D
         const size_t p = (size_t)row * C.W + x;
         const float4 acc = Wk.pixAcc[p];
         float r = acc.x, g = acc.y, b = acc.z;
-        const uint32_t nroots = __float_as_uint(acc.w);
+        /* roots of the pixel, in sample order: slots 0 .. n-1, and - a tile two waves of k_primary shared - the whole
+         * second half of its samples behind them, from slot (sqrtSpp / 2) * sqrtSpp on */
+        const uint32_t word = __float_as_uint(acc.w), n_first = word & ~RT_ROOTS_SPLIT;
+        const uint32_t second = (C.sqrtSpp / 2u) * C.sqrtSpp;
+        const bool split = PAIRS && (word & RT_ROOTS_SPLIT) != 0u;
+        const uint32_t nroots = split ? n_first + (C.sqrtSpp * C.sqrtSpp - second) : n_first;
+        const uint32_t skip = split ? second - n_first : 0u; /* slots between the two runs of roots */
         /* sixteen root ids at a time (one round trip for a whole 4x4-sample pixel), then their node
          * words four roots at a time, all loads of a step independent; the sums in root order */
         for (uint32_t k0 = 0; k0 < nroots; k0 += 16u) {
             uint32_t id[16];
 #pragma unroll
-            for (uint32_t u = 0; u < 16u; ++u)
-                id[u] = Wk.roots[(size_t)min(k0 + u, nroots - 1u) * npix + p];
+            for (uint32_t u = 0; u < 16u; ++u) {
+                const uint32_t k = min(k0 + u, nroots - 1u);
+                id[u] = Wk.roots[(size_t)(k + (k >= n_first ? skip : 0u)) * npix + p];
+            }
 #pragma unroll
             for (uint32_t g4 = 0; g4 < 16u; g4 += 4u) {
                 if (k0 + g4 >= nroots)
@@ -2466,9 +2511,19 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DevCamera C, DevWork Wk, D
                     const uint32_t j = id[g4 + u] < Wk.cap ? id[g4 + u] : 0u;
                     A[u] = Wk.nodeA()[j]; K[u] = Wk.nodeK()[j]; cr[u] = Wk.childR()[j]; ct[u] = Wk.childT()[j];
                 }
+                if (PAIRS && split && R.leaf2) { /* (wave-uniform: a tile is shared or not) finished samples of the second wave */
+#pragma unroll
+                    for (uint32_t u = 0; u < 4u; ++u) {
+                        const uint32_t k = min(k0 + g4 + u, nroots - 1u);
+                        if (id[g4 + u] == RT_LEAF_ROOT && k >= n_first)
+                            A[u] = R.leaf2[(size_t)(k - n_first) * npix + p];
+                    }
+                }
 #pragma unroll
                 for (uint32_t u = 0; u < 4u; ++u) {
-                    if (k0 + g4 + u < nroots && id[g4 + u] < Wk.cap) {
+                    if (PAIRS && k0 + g4 + u < nroots && id[g4 + u] == RT_LEAF_ROOT) {
+                        r = r + A[u].x; g = g + A[u].y; b = b + A[u].z; /* a finished colour, clamped where it was made */
+                    } else if (k0 + g4 + u < nroots && id[g4 + u] < Wk.cap) {
                         float c[3];
                         fold_values(A[u], K[u], cr[u], ct[u], c);
                         r = r + c[0]; g = g + c[1]; b = b + c[2];
@@ -2621,7 +2676,10 @@ void rt_launch_primary_fast(const DevScene &S, const DevCamera &C, const DevWork
         : rt_scene_shape(S) == 1 ? k_primary<false, false, true, 1>
         : S.tabInLds ? k_primary<false, false, true, 0> : k_primary<false, false, false, 0>;
     static const size_t pad_to = [] { const char *e = getenv("RT_HIP_PRIMARY_LDS"); return e ? (size_t)atol(e) : 0; }(); /* as in rt_launch_primary */
-    kernel<<<grid, RT_BLOCK, lds < pad_to && pad_to <= 65536 ? pad_to : lds, stream>>>(S, C, Wk, R);
+    if (R.plan) /* (a plan is a list of blocks) */
+        kernel<<<R.plan_len, RT_BLOCK, lds < pad_to && pad_to <= 65536 ? pad_to : lds, stream>>>(S, C, Wk, R);
+    else
+        kernel<<<grid, RT_BLOCK, lds < pad_to && pad_to <= 65536 ? pad_to : lds, stream>>>(S, C, Wk, R);
 }
 #else
 void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
@@ -2635,7 +2693,10 @@ void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk,
             grid_scene ? (stats ? k_primary<true, true, false, 0, true> : k_primary<true, false, false, 0, true>)
             : S.tabInLds ? (stats ? k_primary<false, true, true, 0, true> : k_primary<false, false, true, 0, true>)
                          : (stats ? k_primary<false, true, false, 0, true> : k_primary<false, false, false, 0, true>);
-        kernel<<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, R);
+        if (R.plan)
+            kernel<<<R.plan_len, RT_BLOCK, lds, stream>>>(S, C, Wk, R);
+        else
+            kernel<<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, R);
         return;
     }
     /* three scene classes: small (everything in LDS), mid (spheres in LDS, tables in HBM), grid (spheres in HBM) */
@@ -2648,7 +2709,10 @@ void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk,
      * blocks per CU instead of seven, i.e. a free block slot (LDS, 80 VGPRs) on every CU for the kernels of
      * a tail stream, which otherwise get in only when a block of this kernel retires */
     static const size_t pad_to = [] { const char *e = getenv("RT_HIP_PRIMARY_LDS"); return e ? (size_t)atol(e) : 0; }();
-    kernel<<<grid, RT_BLOCK, lds < pad_to && pad_to <= 65536 ? pad_to : lds, stream>>>(S, C, Wk, R);
+    if (R.plan)
+        kernel<<<R.plan_len, RT_BLOCK, lds < pad_to && pad_to <= 65536 ? pad_to : lds, stream>>>(S, C, Wk, R);
+    else
+        kernel<<<grid, RT_BLOCK, lds < pad_to && pad_to <= 65536 ? pad_to : lds, stream>>>(S, C, Wk, R);
 }
 #endif
 
@@ -2768,7 +2832,11 @@ void rt_launch_resolve(const DevCamera &C, const DevWork &Wk, const DevRows &R, 
         grid = RT_RESOLVE_GRID;
     if (grid == 0)
         grid = 1;
-    k_resolve<<<(uint32_t)grid, RT_BLOCK, 0, stream>>>(C, Wk, R, d_argb, d_radiance);
+    const bool pairs = R.plan && R.plan_len > (uint32_t)((C.W + 31u) / 32u) * R.ntiles;
+    if (pairs)
+        k_resolve<true><<<(uint32_t)grid, RT_BLOCK, 0, stream>>>(C, Wk, R, d_argb, d_radiance);
+    else
+        k_resolve<false><<<(uint32_t)grid, RT_BLOCK, 0, stream>>>(C, Wk, R, d_argb, d_radiance);
 }
 
 void rt_launch_selftest_arith(const float *a, const float *b, const float *c, uint32_t n, float *out,

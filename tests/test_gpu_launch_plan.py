@@ -166,3 +166,59 @@ def test_plan_survives_an_overflow_retry(torch_cuda, make_scene):
         if st.overflow_retries:
             assert st.plan_builds == 0
     ctx.close()
+
+
+@pytest.mark.parametrize("numerics", [rt.NUMERICS_EXACT, rt.NUMERICS_FAST])
+@pytest.mark.parametrize("name,W,H,s,d", [("builtin", 640, 360, 2, 6), ("builtin", 333, 217, 4, 8), ("builtin", 200, 120, 3, 4),
+                                          ("syn300", 256, 160, 2, 5), ("syn3000", 160, 96, 2, 3)])
+def test_paired_blocks_equal_raster_frames(torch_cuda, make_scene, numerics, name, W, H, s, d):
+    """set_launch_plan(3): every block of the plan is launched twice and the two share the tiles' sample rows (an
+    odd number of rows: the second block leaves).  Same pixels, radiance bits and ray counters."""
+    sc = make_scene(name)
+    cam = rt.prepare_camera(sc, W, H, s, d)
+    plain = rt.Context(queue_cap=1 << 22)
+    plain.upload(sc)
+    plain.set_numerics(numerics)
+    plain.set_launch_plan(False)
+    ctx = rt.Context(queue_cap=1 << 22)
+    ctx.upload(sc)
+    ctx.set_numerics(numerics)
+    ctx.set_launch_plan(3)
+    nblocks = ((W + 31) // 32) * ((H + 7) // 8)
+    for k in range(3):
+        want_a, want_r, st0 = render_dev(torch_cuda, plain, cam)
+        a, r, st = render_dev(torch_cuda, ctx, cam)
+        assert np.array_equal(a, want_a) and np.array_equal(r.view(np.uint32), want_r.view(np.uint32)), k
+        assert counters(st) == counters(st0)
+        assert st.overflow_retries == 0 and st.batches == 1
+        if k == 0:
+            assert st.plan_builds == 1 and st.plan_pairs == (nblocks if s % 2 == 0 else 0)
+        else:
+            assert st.planned_launches == 1
+    ctx.close()
+    plain.close()
+
+
+def test_small_launches_pair_their_slow_blocks_by_themselves(torch_cuda, make_scene):
+    """a launch that does not fill the GPU is as long as its slowest wave: the plan pairs the blocks that take
+    more than 20 us (mode 2)"""
+    sc = make_scene("builtin")
+    cam = rt.prepare_camera(sc, 640, 360, 4, 8)
+    plain = rt.Context(queue_cap=1 << 23)
+    plain.upload(sc)
+    plain.set_launch_plan(False)
+    want_a, want_r, st0 = render_dev(torch_cuda, plain, cam)
+    ctx = rt.Context(queue_cap=1 << 23)
+    ctx.upload(sc)
+    ctx.set_launch_plan(2)
+    pairs = None
+    for k in range(3):
+        a, r, st = render_dev(torch_cuda, ctx, cam)
+        assert np.array_equal(a, want_a) and np.array_equal(r.view(np.uint32), want_r.view(np.uint32)), k
+        assert counters(st) == counters(st0)
+        if k == 0:
+            pairs = st.plan_pairs
+    nblocks = (640 // 32) * (360 // 8)
+    assert 0 < pairs < nblocks, pairs  # the sphere tiles, not the sky
+    ctx.close()
+    plain.close()
