@@ -156,7 +156,7 @@ def main():
                          "grows to N x the pixels")
     ap.add_argument("--sqrt-spp", type=int, default=None)
     ap.add_argument("--depth", type=int, default=None)
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=None,
                     help="frames submitted ahead (each with its own render context) on ONE render stream plus ONE tail "
                          "stream: three keep the host two frames ahead of the GPU, so that the next k_primary is queued "
                          "when the render stream falls free (two: 0.228 ms per frame, three: 0.225, four: 0.220)")
@@ -170,6 +170,12 @@ def main():
                          "(k_primary alone 0.099 against 0.124 ms, 0.106 against 0.125 ms in the pipelined run); pairs: and the slow "
                          "blocks of launches that do not fill the GPU as pairs (mode 2: a rank's eighth of config 3, "
                          "k_primary 0.062 against 0.094 ms, but the frame loop there is bound by the host: 0.166 against 0.153 ms)")
+    ap.add_argument("--shared-stream", action="store_true",
+                    help="with more than one rank: the one-rank arrangement (frames on ONE render stream + a tail stream, three "
+                         "in flight) instead of --overlap with six in flight.  A rank's share of a frame spread over N GPUs "
+                         "does not fill its GPU, and half of its kernels are bound by latency, whatever their size: frames "
+                         "that may overlap freely make up for it (a rank of 8 / 4 / 2 on config 3, rehearsed on one GPU: "
+                         "0.118 / 0.192 / 0.336 ms per frame against 0.151 / 0.200 / 0.382)")
     ap.add_argument("--overlap", action="store_true",
                     help="give every in-flight frame its own stream (kernels of neighbouring frames overlap; the "
                          "event-timed k_primary duration then includes the sharing and is not a clean roofline input)")
@@ -226,7 +232,9 @@ def main():
     # `inflight` frames are submitted ahead: each has its own render context (ray queues, node pool,
     # counters) and frame buffers.  By default they share one HIP stream: the GPU runs the frames back
     # to back while the host collects frame k's counters and submits frame k+2.
-    inflight = max(1, args.inflight)
+    if world > 1 and not args.shared_stream:
+        args.overlap = True
+    inflight = max(1, args.inflight if args.inflight is not None else (6 if args.overlap and world > 1 else 3))
     tail = torch.cuda.Stream(device=dev) if args.tail_stream == "on" and not args.overlap else None
     ctxs = []
     for _ in range(inflight):

@@ -72,20 +72,29 @@ class FrameGather:
         # 32-bit pixel frames on the GPU are de-interleaved by the library's streaming kernel
         self._native = (self.gathered.is_cuda and not trailing and self.gathered.element_size() == 4)
 
-    def gather(self, group=None, collective=True):
-        import torch.distributed as dist
-        if self.plan.world > 1 and collective:
-            dist.all_gather_into_tensor(self.gathered.view(-1), self.local.reshape(-1), group=group)
-        return self.rebuild()
-
-    def rebuild(self):
-        """gathered -> frame on the current stream"""
+        # (views and addresses made once: a rank of eight submits a frame every 0.15 ms, and the host is what bounds it)
+        self._flat = (self.gathered.view(-1), self.local.reshape(-1))
+        self._ptrs = (self.gathered.data_ptr(), self.frame.data_ptr())
         if self._native:
             from . import _lib
-            st = torch.cuda.current_stream(self.gathered.device).cuda_stream
-            _lib.check(_lib.load().rt_hip_deinterleave(self.gathered.data_ptr(), self.frame.data_ptr(), self.width,
-                                                       self.plan.height, self.plan.world, st),
-                       "rt_hip_deinterleave")
+            self._deinterleave = _lib.load().rt_hip_deinterleave
+
+    def gather(self, group=None, collective=True, stream=None):
+        """all-gather (on the current stream) + de-interleave (on `stream`, default the current one)"""
+        if self.plan.world > 1 and collective:
+            import torch.distributed as dist
+            dist.all_gather_into_tensor(self._flat[0], self._flat[1], group=group)
+        return self.rebuild(stream)
+
+    def rebuild(self, stream=None):
+        """gathered -> frame on `stream` (a raw stream handle; default: the current stream)"""
+        if self._native:
+            if stream is None:
+                stream = torch.cuda.current_stream(self.gathered.device).cuda_stream
+            rc = self._deinterleave(self._ptrs[0], self._ptrs[1], self.width, self.plan.height, self.plan.world, stream)
+            if rc:
+                from . import _lib
+                _lib.check(rc, "rt_hip_deinterleave")
             return self.frame
         return deinterleave(self.gathered, self.plan, out=self.frame)
 
@@ -158,19 +167,23 @@ class FramePipeline:
     def submit(self, i):
         k = i % self.inflight
         st, fg = self.streams[k], self.gathers[k]
-        with self._on(st):
-            if self.plan.world == 1:
-                self.render_fn(i, k, fg.frame, st)  # one rank: straight into the frame, nothing to gather
-                return
-            if i >= self.inflight:
-                st.wait_event(self.gathered[k])  # the previous gather out of this slot's buffers is done
-            self.render_fn(i, k, fg.local, st)
-            self.rendered[k].record(self.done_stream if self.done_stream is not None else st)
+        # (render_fn is handed its stream; no stream context around it: entering and leaving one costs the host
+        # 10 us a frame, and with more than one rank the host is what bounds the frame rate)
+        if self.plan.world == 1:
+            self.render_fn(i, k, fg.frame, st)  # one rank: straight into the frame, nothing to gather
+            return
+        if i >= self.inflight:
+            st.wait_event(self.gathered[k])  # the previous gather out of this slot's buffers is done
+        self.render_fn(i, k, fg.local, st)
+        self.rendered[k].record(self.done_stream if self.done_stream is not None else st)
         comm = self.comm if self.comm is not None else st
-        with self._on(comm):
-            comm.wait_event(self.rendered[k])
-            fg.gather(group=self.group, collective=self.collective)  # in-place all-gather + de-interleave
-            self.gathered[k].record(comm)
+        comm.wait_event(self.rendered[k])
+        if self.collective and self.cuda:
+            with torch.cuda.stream(comm):  # (the collective runs on the current stream)
+                fg.gather(group=self.group, collective=True, stream=comm.cuda_stream)
+        else:
+            fg.gather(group=self.group, collective=self.collective, stream=comm.cuda_stream if self.cuda else None)
+        self.gathered[k].record(comm)
 
     def collect(self, i):
         k = i % self.inflight

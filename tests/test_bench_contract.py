@@ -55,6 +55,15 @@ def test_rank_of_a_two_gpu_run_rehearsed_on_one_gpu(gather, tail):
     # N > 1 renders BASELINE config 3 by default: the 3840x2160 frame, fixed, split over the ranks
     assert d["scaling"] == "strong" and d["config"]["workload"].startswith("c3:") and "3840x2160" in d["config"]["workload"]
     assert d["config"]["numerics"] == "fast"
+    # more than one rank: every frame in flight on a stream of its own, six of them (a rank's share does not fill its GPU)
+    assert d["config"]["streams"] == "one per frame" and d["config"]["frames_in_flight"] == 6
+
+
+def test_rank_of_a_multi_gpu_run_on_the_shared_stream():
+    d = run_bench(["--gpus", "4", "--steps", "6", "--warmup", "2", "--shared-stream"],
+                  {"RT_BENCH_REHEARSE_WORLD": "4", "RT_BENCH_REHEARSE_RANK": "2"})
+    assert d["n_gpus"] == 4 and d["config"]["streams"] == "shared + tail stream" and d["config"]["frames_in_flight"] == 3
+    assert d["value"] > 1e4
 
 
 def test_other_workloads_and_weak_scaling_are_selectable():
