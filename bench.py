@@ -32,6 +32,9 @@ Three frames are in flight (a render context each), on ONE render stream of high
 bounce levels, back to back - and ONE tail stream for every frame's sparse deep end (k_subtree), folds, resolve
 and publish, which drain beside the next frame's kernels.  `roofline` times k_primary inside that timed region;
 `roofline.one_frame_at_a_time` is the same kernel with each frame alone on the GPU.
+With more than one rank (a rank's share of the frame does not fill its GPU, and half of a frame's kernels are bound
+by latency whatever their size) SIX frames are in flight, each on a stream of its own (--overlap --inflight 6;
+--shared-stream: the one-rank arrangement); the k_primary of such a run shares the GPU with its neighbours' kernels.
 """
 import argparse
 import json
