@@ -222,3 +222,48 @@ def test_small_launches_pair_their_slow_blocks_by_themselves(torch_cuda, make_sc
     assert 0 < pairs < nblocks, pairs  # the sphere tiles, not the sky
     ctx.close()
     plain.close()
+
+
+def test_random_scenes_with_every_block_a_pair(torch_cuda):
+    """80 random cases - scenes of all three kernel classes, lights off, the eye moved at random, ragged frames,
+    1-4 sample rows, depth 0-10 - rendered with the raster and, three times, with every block of the launch plan a
+    pair: no pixel may differ in any bit, no counter at all."""
+    rng = np.random.default_rng(20261111)
+    for case in range(80):
+        cls = int(rng.integers(0, 4))
+        if cls == 0:
+            sc, desc = rt.Scene.builtin(), "builtin"
+        else:
+            n_sph = int([rng.integers(0, 40), rng.integers(40, 600), rng.integers(2049, 3200)][cls - 1])
+            n_pol = int(rng.integers(0, 5)) or int(n_sph == 0)
+            n_l = int(rng.choice([1, 1, 2, 3, 8, 33])) if cls < 3 else int(rng.integers(1, 4))
+            args = (int(rng.integers(1, 2**31)), n_sph, n_pol, n_l, int(rng.integers(0, 2)))
+            sc, desc = rt.Scene.synthetic(*args), f"synthetic{args}"
+        if rng.random() < 0.1:
+            sc.c.nLights = 0
+        if rng.random() < 0.5:
+            sc.c.eyePos.x += float(rng.normal(0, 2))
+            sc.c.eyePos.y += float(rng.normal(0, 1))
+            sc.c.eyePos.z += float(rng.normal(0, 6))
+        big = cls == 3
+        W, H = int(rng.integers(1, 60 if big else 150)), int(rng.integers(1, 40 if big else 100))
+        s, d = int(rng.choice([1, 2, 2, 3, 4, 4])), int(rng.integers(0, 11))
+        cam = rt.prepare_camera(sc, W, H, s, d)
+        numerics = rt.NUMERICS_FAST if rng.random() < 0.3 else rt.NUMERICS_EXACT
+        plain = rt.Context(queue_cap=1 << 21)
+        plain.upload(sc)
+        plain.set_numerics(numerics)
+        plain.set_launch_plan(0)
+        ctx = rt.Context(queue_cap=1 << 21)
+        ctx.upload(sc)
+        ctx.set_numerics(numerics)
+        ctx.set_launch_plan(3)
+        for k in range(3):
+            want_a, want_r, st0 = render_dev(torch_cuda, plain, cam)
+            a, r, st = render_dev(torch_cuda, ctx, cam)
+            what = f"case {case} render {k}: {W}x{H} s{s} d{d} {desc} numerics {numerics}"
+            assert np.array_equal(a, want_a) and np.array_equal(r.view(np.uint32), want_r.view(np.uint32)), what
+            assert counters(st) == counters(st0), what
+            assert st.overflow_retries == 0 and st0.overflow_retries == 0, what
+        ctx.close()
+        plain.close()
