@@ -174,7 +174,7 @@ def main():
                          "blocks of launches that do not fill the GPU as pairs (mode 2: a rank's eighth of config 3, "
                          "k_primary 0.062 against 0.094 ms, but the frame loop there is bound by the host: 0.166 against 0.153 ms)")
     ap.add_argument("--shared-stream", action="store_true",
-                    help="with more than one rank, or a frame of under 8 Mi samples: the arrangement of config 2 on one GPU (frames "
+                    help="with more than one rank, or a workload other than config 2: the arrangement of config 2 on one GPU (frames "
                          "on ONE render stream + a tail stream, three in flight) instead of --overlap with six in flight.  A rank's share of a frame spread over N GPUs "
                          "does not fill its GPU, and half of its kernels are bound by latency, whatever their size: frames "
                          "that may overlap freely make up for it (a rank of 8 / 4 / 2 on config 3, rehearsed on one GPU: "
@@ -235,8 +235,13 @@ def main():
     # `inflight` frames are submitted ahead: each has its own render context (ray queues, node pool,
     # counters) and frame buffers.  By default they share one HIP stream: the GPU runs the frames back
     # to back while the host collects frame k's counters and submits frame k+2.
-    # frames that do not fill the GPU (a rank's share of a frame over N GPUs; config 1's 0.3 M samples) overlap freely
-    if (world > 1 or W * H * sqrt_spp * sqrt_spp < (8 << 20)) and not args.shared_stream:
+    # Frames that may overlap freely (a stream each, six in flight) give the highest throughput on every workload: a
+    # rank's share of a frame over N GPUs and the small frames do not fill the GPU, and the 4K frames have long
+    # latency-bound tails (config 3 on one GPU 0.775 -> 0.631 ms, config 4 55.9 -> 52.1 ms, config 5's scene 54.8 -> 46.8,
+    # config 1 0.056 -> 0.024).  Config 2 on one GPU - the configuration the metric is quoted on - gains 3-5 % that
+    # way (0.180-0.184 against 0.190 ms) and keeps ONE high-priority render stream instead, so that the event-timed
+    # k_primary of the roofline is the kernel and not the kernel plus its neighbours (0.106 against 0.18-0.21 ms).
+    if (world > 1 or cfg != "c2") and not args.shared_stream:
         args.overlap = True
     inflight = max(1, args.inflight if args.inflight is not None else (6 if args.overlap else 3))
     tail = torch.cuda.Stream(device=dev) if args.tail_stream == "on" and not args.overlap else None
