@@ -288,9 +288,14 @@ def main():
     # set-up, before the W warm-up steps: every context renders the frame twice - a context sizes its queues from
     # its first frame, times its tiles for k_primary's launch plan, and plans the sparse levels of the tree
     # (k_subtree, k_fold_deep) from the second on
-    for i in range(2 * inflight):
+    # ... and goes on, for at most 30 ms, until the GPU's clocks have settled (the first ~20 frames of a process run
+    # 5 % slow: a short --warmup would otherwise be timed on a GPU that is still ramping up)
+    t_setup = time.perf_counter()
+    i = 0
+    while i < 2 * inflight or (i < 64 and time.perf_counter() - t_setup < 0.03):
         pipe.submit(i)
         pipe.collect(i)
+        i += 1
     for i in range(warmup):
         pipe.submit(i)
         pipe.collect(i)
