@@ -77,6 +77,9 @@ struct rt_hip_ctx {
     size_t pix_cap = 0, tile_cap = 0;
     uint32_t *roots = nullptr; /* [spp^2][pixels of a batch] */
     size_t roots_cap = 0;
+    /* the job pipeline of big scenes (rt_jobs.inc): per-sample arrays of a batch, allocated when first needed */
+    DevLevel0 Z{};
+    size_t z_samples = 0, z_vis = 0; /* samples / visibility bytes the arrays hold */
     uint32_t *d_counters = nullptr; /* [kMaxBatches][RT_COUNTER_WORDS] */
     uint32_t *h_counters = nullptr; /* pinned, device-mapped mirror (written by k_publish) */
     uint32_t *h_counters_dev = nullptr; /* its device address */
@@ -211,6 +214,42 @@ int ensure_pix(rt_hip_ctx *c, size_t npix, size_t spp2)
     return 0;
 }
 
+/* Big scenes (a sphere grid) render through the job pipeline (rt_jobs.inc) - but for the instrumented and the
+ * phong-blinn renders, which the fused kernels do, and scenes with more lights than its visibility bytes hold. */
+bool jobs_path(const rt_hip_ctx *c, bool stats)
+{
+    static const bool off = getenv("RT_HIP_NO_JOBS") != nullptr; /* development: the fused kernels for every scene */
+    return !off && c->S.grid != nullptr && !stats && c->shading == RT_SHADE_PHONG && c->S.nLights <= RT_JOBS_MAX_LIGHTS;
+}
+
+int ensure_level0(rt_hip_ctx *c, size_t npix, size_t spp2)
+{
+    const size_t samples = npix * spp2, vis = samples * (c->S.nLights ? c->S.nLights : 1u);
+    if (samples > 0xFFFFFFFFull) {
+        set_err("a batch of %zu samples does not fit the job pipeline's 32-bit sample index", samples);
+        return RT_E_INVALID;
+    }
+    if (samples > c->z_samples) {
+        if (c->Z.hit) HIP_TRY(hipFree(c->Z.hit));
+        if (c->Z.childR) HIP_TRY(hipFree(c->Z.childR));
+        if (c->Z.childT) HIP_TRY(hipFree(c->Z.childT));
+        c->Z.hit = nullptr; c->Z.childR = c->Z.childT = nullptr;
+        c->z_samples = 0;
+        HIP_TRY(hipMalloc((void **)&c->Z.hit, samples * sizeof(uint2)));
+        HIP_TRY(hipMalloc((void **)&c->Z.childR, samples * sizeof(float4)));
+        HIP_TRY(hipMalloc((void **)&c->Z.childT, samples * sizeof(float4)));
+        c->z_samples = samples;
+    }
+    if (vis > c->z_vis) {
+        if (c->Z.vis) HIP_TRY(hipFree(c->Z.vis));
+        c->Z.vis = nullptr;
+        c->z_vis = 0;
+        HIP_TRY(hipMalloc((void **)&c->Z.vis, vis));
+        c->z_vis = vis;
+    }
+    return 0;
+}
+
 DevRows rows_of(const rt_hip_ctx *c, const Batch &b)
 {
     const Job &j = c->job;
@@ -313,6 +352,37 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
     }
     /* the tolerance build has the plain Phong kernels only: instrumented and phong-blinn renders run the exact ones */
     const bool fast = c->numerics == RT_NUMERICS_FAST && !stats && c->shading == RT_SHADE_PHONG;
+    if (jobs_path(c, stats)) {
+        /* Big scenes: rays as jobs (rt_jobs.inc).  The samples' closest hits, then per level the shadow and child
+         * rays of its hits, then the colours from the deepest level up, then the pixels; all on the render stream.
+         * The events bracket the level-0 work the fused k_primary would do: the primary rays and the rays of
+         * their hits. */
+        DevLevel0 Z = c->Z;
+        Z.npix = R.ntiles * 8u * c->C.W;
+        Z.nsamples = Z.npix * c->C.sqrtSpp * c->C.sqrtSpp;
+        const bool known = c->seen_valid;
+        uint32_t last = depth; /* deepest level that may hold hits */
+        if (known)
+            while (last > 0u && c->seen_hits[last] == 0u)
+                --last;
+        if (known && last < depth)
+            ++last; /* (one level of margin: an empty level's kernels return at once) */
+        (fast ? rt_launch_jobs_hits_fast : rt_launch_jobs_hits)(c->S, c->C, Wk, R, Z, st);
+        for (uint32_t d = 0; d <= last; ++d) {
+            const uint32_t expect = d == 0u ? 0u : known ? (c->seen_hits[d] ? c->seen_hits[d] : 1u) : 0u;
+            (fast ? rt_launch_jobs_trace_fast : rt_launch_jobs_trace)(c->S, c->C, Wk, R, Z, d, expect, st);
+            if (d == 0u && timed)
+                HIP_TRY(hipEventRecord(c->ev.back(), st));
+        }
+        for (uint32_t d = last; d >= 1u; --d) {
+            const uint32_t expect = known ? (c->seen_hits[d] ? c->seen_hits[d] : 1u) : 0u;
+            (fast ? rt_launch_jobs_shadefold_fast : rt_launch_jobs_shadefold)(c->S, c->C, Wk, Z, d, expect, st);
+        }
+        (fast ? rt_launch_jobs_resolve_fast : rt_launch_jobs_resolve)(c->S, c->C, Wk, R, Z, st);
+        rt_launch_publish(Wk.counters, c->h_counters_dev + (size_t)b.slot * c->cwords, (uint32_t)c->cwords, st);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (R.plan)
         c->stats.planned_launches++;
     if (fast)
@@ -895,6 +965,10 @@ void rt_hip_ctx_destroy(rt_hip_ctx *c)
     if (c->tile_done) (void)hipFree(c->tile_done);
     if (c->leaf2) (void)hipFree(c->leaf2);
     if (c->roots) (void)hipFree(c->roots);
+    if (c->Z.hit) (void)hipFree(c->Z.hit);
+    if (c->Z.vis) (void)hipFree(c->Z.vis);
+    if (c->Z.childR) (void)hipFree(c->Z.childR);
+    if (c->Z.childT) (void)hipFree(c->Z.childT);
     if (c->d_plan) (void)hipFree(c->d_plan);
     if (c->d_wave_ticks) (void)hipFree(c->d_wave_ticks);
     if (c->d_counters) (void)hipFree(c->d_counters);
@@ -1446,10 +1520,11 @@ static int submit(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb, float *
         return 0;
     const uint32_t per = tiles_per_batch(c, default_batch_samples(c));
     const uint32_t most = per < job.ntiles ? per : job.ntiles;
-    rc = ensure_pix(c, (size_t)most * 8u * c->C.W, (size_t)c->C.sqrtSpp * c->C.sqrtSpp);
+    rc = jobs_path(c, job.stats) ? ensure_level0(c, (size_t)most * 8u * c->C.W, (size_t)c->C.sqrtSpp * c->C.sqrtSpp)
+                                 : ensure_pix(c, (size_t)most * 8u * c->C.W, (size_t)c->C.sqrtSpp * c->C.sqrtSpp);
     if (rc)
         return rc;
-    rc = plan_frame(c, per >= job.ntiles);
+    rc = plan_frame(c, per >= job.ntiles && !jobs_path(c, job.stats));
     if (rc)
         return rc;
     for (uint32_t t = job.ntiles; t > 0;) { /* pushed back to front: the list is popped from the end */

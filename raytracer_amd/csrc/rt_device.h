@@ -162,6 +162,18 @@ struct DevWork {
     __host__ __device__ __forceinline__ float2 *nodeK() const { return (float2 *)slot(9u); }
 };
 
+/* Per-sample arrays of a batch of a BIG scene (the job pipeline, rt_jobs.inc): sample = k * npix + pixel of the
+ * batch, k = j * sqrtSpp + i the sub-sample in the reference's order (raytrace.c:746-776). */
+struct DevLevel0 {
+    uint2 *hit;        /* [nsamples] (object hit by the primary ray or RT_NONE, bits of the distance along it) */
+    uint8_t *vis;      /* [nLights][nsamples] 1: the shadow ray to that light met nothing                        */
+    float4 *childR;    /* [nsamples] colour the reflection ray brought back (the deeper levels use DevWork's)    */
+    float4 *childT;    /* [nsamples] ... the transmission ray                                                    */
+    uint32_t nsamples; /* sqrtSpp^2 * npix                                                                       */
+    uint32_t npix;     /* pixels of the batch: its tile rows x 8 x W                                             */
+};
+#define RT_JOBS_MAX_LIGHTS 32u /* visibility bytes of the deeper levels: two slots of 16 bytes an entry */
+
 /*
  * Counter block of a batch (uint32 words).  Zero when a batch starts: k_publish, the last kernel of every
  * batch, copies the block to the host's mapped mirror and zeroes it for its next use (the host clears
@@ -236,6 +248,23 @@ void rt_launch_fold(const DevWork &Wk, uint32_t level, uint32_t expect, hipStrea
 void rt_launch_resolve(const DevCamera &C, const DevWork &Wk, const DevRows &R, uint32_t *d_argb,
                        float *d_radiance, hipStream_t stream);
 size_t rt_scene_lds_bytes(const DevScene &S);
+/* the job pipeline of big scenes (rt_jobs.inc), exact build and tolerance build (`_fast`) */
+void rt_launch_jobs_hits(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
+                         const DevLevel0 &Z, hipStream_t stream);
+void rt_launch_jobs_trace(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
+                          const DevLevel0 &Z, uint32_t level, uint32_t expect, hipStream_t stream);
+void rt_launch_jobs_shadefold(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevLevel0 &Z,
+                              uint32_t level, uint32_t expect, hipStream_t stream);
+void rt_launch_jobs_resolve(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
+                            const DevLevel0 &Z, hipStream_t stream);
+void rt_launch_jobs_hits_fast(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
+                              const DevLevel0 &Z, hipStream_t stream);
+void rt_launch_jobs_trace_fast(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
+                               const DevLevel0 &Z, uint32_t level, uint32_t expect, hipStream_t stream);
+void rt_launch_jobs_shadefold_fast(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevLevel0 &Z,
+                                   uint32_t level, uint32_t expect, hipStream_t stream);
+void rt_launch_jobs_resolve_fast(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
+                                 const DevLevel0 &Z, hipStream_t stream);
 void rt_launch_selftest_grid(const DevScene &S, const float *rays, uint32_t n, bool filtered, uint32_t *out,
                              hipStream_t stream);
 int rt_scene_shape(const DevScene &S); /* 0 = generic kernels, else the specialisation (rt_kernels.hip) */

@@ -2371,6 +2371,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_subtree(DevScene S, DevCamera C, D
     wave_add_total(st, ST_KB_TRANS, sc.trans);
 }
 
+#include "rt_jobs.inc" /* the pipeline of big scenes: rays as jobs of persistent lanes */
+
 #ifndef RT_FAST /* the kernels below do no arithmetic a tolerance could speed up: one copy, shared by both builds */
 /* colour of a tree node once both children are known: raytrace.c:440-442, 547-549, 562 */
 __device__ __forceinline__ uint32_t fold_values(const float4 A, const float2 K, const float4 cr,
@@ -2883,6 +2885,42 @@ void rt_launch_publish(uint32_t *counters, uint32_t *mirror, uint32_t words, hip
     k_publish<<<(n16 + RT_BLOCK - 1) / RT_BLOCK, RT_BLOCK, 0, stream>>>((uint4 *)counters, (uint4 *)mirror, n16);
 }
 #endif /* RT_FAST */
+
+/* ---- the job pipeline of big scenes (rt_jobs.inc): both builds ---- */
+#ifdef RT_FAST
+#define RT_WRAP(name) name##_fast
+#else
+#define RT_WRAP(name) name
+#endif
+void RT_WRAP(rt_launch_jobs_hits)(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
+                                  const DevLevel0 &Z, hipStream_t stream)
+{
+    const dim3 grid((C.W + 31u) / 32u, R.ntiles);
+    k_hits<<<grid, RT_BLOCK, (size_t)S.nPolySlots * sizeof(float4), stream>>>(S, C, Wk, R, Z);
+}
+/* `expect`: hits per shard the level is expected to hold (0: unknown, or level 0 - a full resident set) */
+void RT_WRAP(rt_launch_jobs_trace)(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
+                                   const DevLevel0 &Z, uint32_t level, uint32_t expect, hipStream_t stream)
+{
+    const size_t lds = (size_t)S.nPolySlots * sizeof(float4);
+    void (*kernel)(DevScene, DevCamera, DevWork, DevRows, DevLevel0, uint32_t) = level == 0u ? k_trace<true> : k_trace<false>;
+    /* a block's four waves work through ~2 rounds of jobs at least: a sparse level gets a small grid */
+    const uint32_t jobs = expect ? (uint32_t)((uint64_t)expect * (S.nLights + 2u) / (2u * RT_BLOCK)) + 1u : 0u;
+    const uint32_t grid = queue_grid(Wk, (const void *)kernel, lds, jobs ? jobs * RT_BLOCK / 2u : 0u);
+    kernel<<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, R, Z, level);
+}
+void RT_WRAP(rt_launch_jobs_shadefold)(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevLevel0 &Z,
+                                       uint32_t level, uint32_t expect, hipStream_t stream)
+{
+    k_shadefold<<<queue_grid(Wk, (const void *)k_shadefold, 0, expect), RT_BLOCK, 0, stream>>>(S, C, Wk, Z, level);
+}
+void RT_WRAP(rt_launch_jobs_resolve)(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
+                                     const DevLevel0 &Z, hipStream_t stream)
+{
+    size_t grid = ((size_t)Z.npix + RT_BLOCK - 1) / RT_BLOCK;
+    grid = grid > 16384 ? 16384 : (grid ? grid : 1);
+    k_resolve_jobs<<<(uint32_t)grid, RT_BLOCK, 0, stream>>>(S, C, Wk, R, Z);
+}
 
 #if defined(RT_TILE_TRACE) && defined(RT_FAST)
 extern "C" int rt_dev_tile_trace_read(void *host, size_t bytes)

@@ -49,7 +49,10 @@ def test_planned_frames_equal_raster_frames(torch_cuda, make_scene, numerics, na
         assert st.batches == 1
         seen.append((st.planned_launches, st.plan_builds))
     # the first frame is timed and the plan built at its end; the others follow it, nothing is rebuilt
-    assert seen == [(0, 1), (1, 0), (1, 0), (1, 0)], seen
+    # (big scenes render through the job pipeline, rt_jobs.inc: persistent lanes take rays from a cursor, there is
+    # no launch order to plan - the frames must still be identical)
+    big = name in ("syn300", "syn3000")
+    assert seen == ([(0, 0)] * 4 if big else [(0, 1), (1, 0), (1, 0), (1, 0)]), seen
     # switched off: back to the raster, same frame
     ctx.set_launch_plan(False)
     a, r, st = render_dev(torch_cuda, ctx, cam)
