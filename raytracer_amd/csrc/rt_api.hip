@@ -79,6 +79,7 @@ struct rt_hip_ctx {
     size_t roots_cap = 0;
     /* the job pipeline of big scenes (rt_jobs.inc): per-sample arrays of a batch, allocated when first needed */
     DevLevel0 Z{};
+    float4 *loopq = nullptr; /* DevWork::loopq */
     size_t z_samples = 0, z_vis = 0; /* samples / visibility bytes the arrays hold */
     uint32_t *d_counters = nullptr; /* [kMaxBatches][RT_COUNTER_WORDS] */
     uint32_t *h_counters = nullptr; /* pinned, device-mapped mirror (written by k_publish) */
@@ -219,7 +220,8 @@ int ensure_pix(rt_hip_ctx *c, size_t npix, size_t spp2)
 bool jobs_path(const rt_hip_ctx *c, bool stats)
 {
     static const bool off = getenv("RT_HIP_NO_JOBS") != nullptr; /* development: the fused kernels for every scene */
-    return !off && c->S.grid != nullptr && !stats && c->shading == RT_SHADE_PHONG && c->S.nLights <= RT_JOBS_MAX_LIGHTS;
+    return !off && c->S.grid != nullptr && (c->S.lgrid != nullptr || c->S.nLights == 0u) && !stats && c->shading == RT_SHADE_PHONG &&
+           c->S.nLights <= RT_JOBS_MAX_LIGHTS;
 }
 
 int ensure_level0(rt_hip_ctx *c, size_t npix, size_t spp2)
@@ -370,7 +372,7 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
         (fast ? rt_launch_jobs_hits_fast : rt_launch_jobs_hits)(c->S, c->C, Wk, R, Z, st);
         for (uint32_t d = 0; d <= last; ++d) {
             const uint32_t expect = d == 0u ? 0u : known ? (c->seen_hits[d] ? c->seen_hits[d] : 1u) : 0u;
-            (fast ? rt_launch_jobs_trace_fast : rt_launch_jobs_trace)(c->S, c->C, Wk, R, Z, d, expect, st);
+            (fast ? rt_launch_jobs_trace_fast : rt_launch_jobs_trace)(c->S, c->C, Wk, R, Z, d, expect, d != depth, st);
             if (d == 0u && timed)
                 HIP_TRY(hipEventRecord(c->ev.back(), st));
         }
@@ -803,7 +805,25 @@ int ensure_work(rt_hip_ctx *c, uint64_t cap)
     c->W.stride = arr;
     c->W.cap = (uint32_t)cap;
     c->W.capS = (uint32_t)(cap / RT_SHARDS);
+    /* the job pipeline's loop queues (big scenes only): an eighth of the log's entries, 64 bytes each */
+    if (c->loopq) {
+        HIP_TRY(hipFree(c->loopq));
+        c->loopq = nullptr;
+    }
+    c->W.loopq = nullptr; /* (ensure_loopq, when a big scene is rendered) */
+    c->W.loop_capS = 0;
     c->seen_valid = false;
+    return 0;
+}
+
+int ensure_loopq(rt_hip_ctx *c)
+{
+    if (c->loopq || !c->cap)
+        return 0;
+    const uint32_t lcap = (uint32_t)(c->cap / RT_SHARDS / 8u) < 256u ? 256u : (uint32_t)(c->cap / RT_SHARDS / 8u);
+    HIP_TRY(hipMalloc((void **)&c->loopq, (size_t)RT_SHARDS * lcap * 4u * sizeof(float4)));
+    c->W.loopq = c->loopq;
+    c->W.loop_capS = lcap;
     return 0;
 }
 
@@ -965,6 +985,7 @@ void rt_hip_ctx_destroy(rt_hip_ctx *c)
     if (c->tile_done) (void)hipFree(c->tile_done);
     if (c->leaf2) (void)hipFree(c->leaf2);
     if (c->roots) (void)hipFree(c->roots);
+    if (c->loopq) (void)hipFree(c->loopq);
     if (c->Z.hit) (void)hipFree(c->Z.hit);
     if (c->Z.vis) (void)hipFree(c->Z.vis);
     if (c->Z.childR) (void)hipFree(c->Z.childR);
@@ -1160,7 +1181,7 @@ namespace {
  * cells per axis; a sphere goes into every cell its grown bounding box overlaps.
  * Returns the words GridHeader | cellStart[cells + 1] | items. */
 void build_grid(const std::vector<float4> &sph, const rt_scene *sc, const std::vector<uint32_t> &sph_obj,
-                std::vector<uint32_t> &words)
+                std::vector<uint32_t> &words, std::vector<double> &grown, double &reach_out)
 {
     const size_t n = sph.size();
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
@@ -1259,11 +1280,165 @@ void build_grid(const std::vector<float4> &sph, const rt_scene *sc, const std::v
                     }
         }
         if (pass == 1) {
-            words.assign(G.words + cells + 1 + items.size(), 0u);
+            /* ... and the cells once more as 64-byte records with their spheres inline (CellRec) */
+            const size_t lists = G.words + cells + 1 + items.size();
+            G.rec_words = (uint32_t)((lists + 3u) & ~(size_t)3u);
+            G.pad_[0] = G.pad_[1] = G.pad_[2] = 0u;
+            words.assign((size_t)G.rec_words + cells * (sizeof(CellRec) / sizeof(uint32_t)), 0u);
             memcpy(words.data(), &G, sizeof G);
             memcpy(words.data() + G.words, count.data(), (cells + 1) * sizeof(uint32_t));
             if (!items.empty())
                 memcpy(words.data() + G.words + cells + 1, items.data(), items.size() * sizeof(uint32_t));
+            CellRec *rec = (CellRec *)(words.data() + G.rec_words);
+            for (size_t ci = 0; ci < cells; ++ci) {
+                const uint32_t beg = count[ci], cnt = count[ci + 1] - beg;
+                if (cnt <= RT_CELL_INLINE) {
+                    rec[ci].count = cnt;
+                    for (uint32_t u = 0; u < cnt; ++u) {
+                        rec[ci].idx[u] = items[beg + u];
+                        rec[ci].sph[u] = sph[items[beg + u]];
+                    }
+                } else {
+                    rec[ci].count = cnt | RT_CELL_LISTED;
+                    rec[ci].idx[0] = beg;
+                }
+            }
+        }
+    }
+    grown.resize(n);
+    for (size_t k = 0; k < n; ++k)
+        grown[k] = sqrt(rad[k] * rad[k] + extra2);
+    reach_out = reach;
+}
+
+/* The lights' direction grids (LightGridHeader in rt_device.h).  `grown`: the radius within which the reference's
+ * test can still accept a sphere around a ray's line (build_grid).  A shadow ray's line passes its light within
+ * eta: the direction is (light - point) * (1 / length), rounded per component, the pushed origin stays on the line. */
+void build_light_grids(const std::vector<float4> &sph, const std::vector<double> &grown, double reach,
+                       const rt_scene *sc, std::vector<uint32_t> &words)
+{
+    const size_t n = sph.size();
+    const uint32_t nL = sc->nLights;
+    words.clear();
+    if (!nL || !n)
+        return;
+    struct Span { int f, a0, a1, b0, b1; };
+    const double kPi = 3.14159265358979323846;
+    uint32_t res = 256;
+    std::vector<uint32_t> count, gcount(nL + 1, 0);
+    std::vector<std::vector<Span>> spans; /* per (light, sphere): the cell rectangles, at most one per face */
+    std::vector<uint8_t> global;
+    for (;; res /= 2) {
+        const size_t ncell = (size_t)6 * res * res;
+        count.assign((size_t)nL * ncell + 1, 0);
+        spans.assign((size_t)nL * n, {});
+        global.assign((size_t)nL * n, 0);
+        double listed = 0.0;
+        for (uint32_t l = 0; l < nL; ++l) {
+            const double L[3] = {sc->lights[l].position.x, sc->lights[l].position.y, sc->lights[l].position.z};
+            const double eta = 1e-5 * (fmax(fabs(L[0]), fmax(fabs(L[1]), fabs(L[2]))) + reach + 1.0);
+            for (size_t k = 0; k < n; ++k) {
+                const double w[3] = {sph[k].x - L[0], sph[k].y - L[1], sph[k].z - L[2]};
+                const double dist = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+                const double R = (grown[k] + eta) * 1.0001;
+                if (!(dist > R * 1.001 + 1e-9)) { /* the light is (nearly) inside: met by lines of every direction */
+                    global[(size_t)l * n + k] = 1;
+                    continue;
+                }
+                const double sa = R / dist;
+                const double u[3] = {w[0] / dist, w[1] / dist, w[2] / dist};
+                for (int m = 0; m < 3; ++m)
+                    for (int neg = 0; neg < 2; ++neg) {
+                        const double um = neg ? -u[m] : u[m];
+                        const int ja = m == 0 ? 1 : 0, jb = m == 2 ? 1 : 2; /* the other two axes, in axis order */
+                        int lohi[2][2];
+                        bool touched = true;
+                        for (int q = 0; q < 2 && touched; ++q) {
+                            const double uj = u[q ? jb : ja];
+                            const double ell = sqrt(um * um + uj * uj);
+                            double lo = -kPi / 4 - 1e-4, hi = kPi / 4 + 1e-4;
+                            const double al = sa < ell * 0.999999 ? asin(sa / ell) + 1e-6 : kPi;
+                            if (al < kPi / 2) {
+                                /* the cone between its two tangent planes that hold the third axis: angles phi -+ al in the
+                                 * plane of these two axes, against [-pi/4, pi/4] (phi in (-pi, pi], al < pi/2: no wrap
+                                 * reaches it); a wider cone is listed across the whole face */
+                                const double phi = atan2(uj, um);
+                                lo = fmax(lo, phi - al);
+                                hi = fmin(hi, phi + al);
+                            }
+                            if (lo > hi) {
+                                touched = false;
+                                break;
+                            }
+                            const double a0 = tan(lo) - 2e-4, a1 = tan(hi) + 2e-4;
+                            long c0 = (long)floor((a0 + 1.0) * 0.5 * res), c1 = (long)floor((a1 + 1.0) * 0.5 * res);
+                            c0 = c0 < 0 ? 0 : (c0 > (long)res - 1 ? (long)res - 1 : c0);
+                            c1 = c1 < 0 ? 0 : (c1 > (long)res - 1 ? (long)res - 1 : c1);
+                            lohi[q][0] = (int)c0;
+                            lohi[q][1] = (int)c1;
+                        }
+                        if (!touched)
+                            continue;
+                        spans[(size_t)l * n + k].push_back({2 * m + neg, lohi[0][0], lohi[0][1], lohi[1][0], lohi[1][1]});
+                        listed += (double)(lohi[0][1] - lohi[0][0] + 1) * (lohi[1][1] - lohi[1][0] + 1);
+                    }
+            }
+        }
+        if (listed <= 16.0 * (double)n * nL || res <= 8)
+            break;
+    }
+    const size_t ncell = (size_t)6 * res * res;
+    auto each_cell = [&](uint32_t l, size_t k, auto &&fn) {
+        for (const Span &sp : spans[(size_t)l * n + k])
+            for (int b = sp.b0; b <= sp.b1; ++b)
+                for (int a = sp.a0; a <= sp.a1; ++a)
+                    fn((size_t)l * ncell + ((size_t)sp.f * res + b) * res + a);
+    };
+    for (uint32_t l = 0; l < nL; ++l)
+        for (size_t k = 0; k < n; ++k)
+            each_cell(l, k, [&](size_t ci) { count[ci]++; });
+    uint32_t run = 0;
+    for (size_t i = 0; i < count.size(); ++i) {
+        const uint32_t c = count[i];
+        count[i] = run;
+        run += c;
+    }
+    for (uint32_t l = 0; l < nL; ++l) { /* the global lists behind the cells' */
+        gcount[l] = run;
+        for (size_t k = 0; k < n; ++k)
+            run += global[(size_t)l * n + k];
+    }
+    gcount[nL] = run;
+    const uint32_t nitems = run;
+    LightGridHeader H;
+    H.res = res;
+    H.ncell = (uint32_t)ncell;
+    H.off_cells = (uint32_t)(sizeof H / sizeof(uint32_t));
+    H.off_gstart = H.off_cells + (uint32_t)count.size();
+    H.off_idx = H.off_gstart + nL + 1;
+    H.off_sph = (H.off_idx + nitems + 3u) & ~3u;
+    H.nitems = nitems;
+    H.pad_ = 0;
+    words.assign((size_t)H.off_sph + (size_t)nitems * 4u, 0u);
+    memcpy(words.data(), &H, sizeof H);
+    memcpy(words.data() + H.off_cells, count.data(), count.size() * sizeof(uint32_t));
+    memcpy(words.data() + H.off_gstart, gcount.data(), gcount.size() * sizeof(uint32_t));
+    uint32_t *idx = words.data() + H.off_idx;
+    float4 *isph = (float4 *)(words.data() + H.off_sph);
+    std::vector<uint32_t> fill(count.begin(), count.end() - 1);
+    for (uint32_t l = 0; l < nL; ++l) {
+        uint32_t g = gcount[l];
+        for (size_t k = 0; k < n; ++k) { /* ascending k: every list comes out sorted */
+            each_cell(l, k, [&](size_t ci) {
+                idx[fill[ci]] = (uint32_t)k;
+                isph[fill[ci]] = sph[k];
+                fill[ci]++;
+            });
+            if (global[(size_t)l * n + k]) {
+                idx[g] = (uint32_t)k;
+                isph[g] = sph[k];
+                ++g;
+            }
         }
     }
 }
@@ -1352,16 +1527,21 @@ int rt_hip_scene_upload(rt_hip_ctx *c, const rt_scene *sc)
         tab[2 * l + 1] = make_float4(L.color.r, L.color.g, L.color.b, 0.f);
     }
 
-    std::vector<uint32_t> grid;
-    if (nSph > RT_TILE_SPHERES)
-        build_grid(sph, sc, sph_obj, grid);
+    std::vector<uint32_t> grid, lgrid;
+    if (nSph > RT_TILE_SPHERES) {
+        std::vector<double> grown;
+        double reach = 0.0;
+        build_grid(sph, sc, sph_obj, grid, grown, reach);
+        if (nL <= RT_JOBS_MAX_LIGHTS)
+            build_light_grids(sph, grown, reach, sc, lgrid);
+    }
 
     /* one blob, 256-B aligned arrays */
     struct Seg { const void *src; size_t bytes; size_t off; };
-    Seg segs[5] = {
+    Seg segs[6] = {
         {sph.data(), sph.size() * sizeof(float4), 0},   {sph_obj.data(), sph_obj.size() * sizeof(uint32_t), 0},
         {poly.data(), poly.size() * sizeof(float4), 0}, {tab.data(), tab.size() * sizeof(float4), 0},
-        {grid.data(), grid.size() * sizeof(uint32_t), 0}};
+        {grid.data(), grid.size() * sizeof(uint32_t), 0}, {lgrid.data(), lgrid.size() * sizeof(uint32_t), 0}};
     size_t total = 0;
     for (Seg &s : segs) {
         s.off = total;
@@ -1392,6 +1572,7 @@ int rt_hip_scene_upload(rt_hip_ctx *c, const rt_scene *sc)
     S.poly = (const float4 *)(b + segs[2].off);
     S.tab = (const float4 *)(b + segs[3].off);
     S.grid = grid.empty() ? nullptr : (const uint32_t *)(b + segs[4].off);
+    S.lgrid = lgrid.empty() ? nullptr : (const uint32_t *)(b + segs[5].off);
     S.nSph = nSph;
     S.nPoly = nPoly;
     S.nPolySlots = (uint32_t)polySlots;
@@ -1520,6 +1701,8 @@ static int submit(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb, float *
         return 0;
     const uint32_t per = tiles_per_batch(c, default_batch_samples(c));
     const uint32_t most = per < job.ntiles ? per : job.ntiles;
+    if (jobs_path(c, job.stats) && (rc = ensure_loopq(c)))
+        return rc;
     rc = jobs_path(c, job.stats) ? ensure_level0(c, (size_t)most * 8u * c->C.W, (size_t)c->C.sqrtSpp * c->C.sqrtSpp)
                                  : ensure_pix(c, (size_t)most * 8u * c->C.W, (size_t)c->C.sqrtSpp * c->C.sqrtSpp);
     if (rc)

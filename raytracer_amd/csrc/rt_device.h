@@ -52,6 +52,7 @@ struct DevScene {
     const uint32_t *grid;     /* scenes with more than RT_TILE_SPHERES spheres: GridHeader, then
                                  cellStart[cells + 1], then the cells' sphere indices (ascending
                                  within a cell); nullptr otherwise                              */
+    const uint32_t *lgrid;    /* with `grid`: the lights' direction grids (LightGridHeader ...), or nullptr */
     uint32_t nSph, nPoly, nPolySlots, nObj, nLights;
     uint32_t tabSlots;        /* 2*nLights + 5*nObj                                          */
     uint32_t tabInLds;        /* the tables are small enough to be staged in LDS per block   */
@@ -79,6 +80,40 @@ struct GridHeader {
     uint32_t words;  /* size of this header in uint32_t  */
     float centre[3]; /* of the box                       */
     float origin_reach2; /* a ray walks the grid only if its origin is within sqrt(this) of the centre */
+    uint32_t rec_words;  /* where the cell records start: words from the grid's base, a multiple of 4 */
+    uint32_t pad_[3];
+};
+/* The same cells once more, one 64-byte record each, for the walks of the job pipeline (rt_jobs.inc): a lane gets a
+ * cell's spheres with ONE round trip instead of three dependent ones (cellStart -> items -> sph).
+ *   count <= 3: the cell's spheres are idx[0 .. count) / sph[0 .. count) (centre, r*r: DevScene::sph's words)
+ *   else      : bit 31 set, count & 0x7fffffff entries of the grid's item list from idx[0] on */
+struct CellRec {
+    uint32_t count;
+    uint32_t idx[3];
+    float4 sph[3];
+};
+#define RT_CELL_INLINE 3u
+#define RT_CELL_LISTED 0x80000000u
+
+/*
+ * Shadow rays end at a light: every sphere such a ray can meet lies in a narrow cone around the ray as seen FROM
+ * the light.  Per light, the directions from it are cut into the cells of a cube map (6 faces of res x res
+ * cells), and a cell lists every sphere whose grown ball (the growth of GridHeader, plus the distance by which a
+ * shadow ray's line can miss its light after float rounding) is touched by some line through the light with a
+ * direction in the cell; spheres that hold the light (nearly) are in the light's "global" list.  A shadow ray's
+ * any-hit search is then ONE cell lookup and a scan of that cell's list and the global list - no walk.  Built by
+ * rt_hip_scene_upload (rt_api.hip, build_light_grids); the same exclusions as the grid: direction of unit length,
+ * origin within the grid's reach.
+ *   words: LightGridHeader | cellStart[nLights * 6 * res * res + 1] | gstart[nLights + 1] | idx[nitems] |
+ *          sph[nitems] (float4: centre, r*r).  Cell lists first, the global lists behind them.
+ * cell of direction u (from the light): m = axis of the largest |u|, face = 2 m + (u[m] < 0),
+ *   (a, b) = the other two components in axis order / |u[m]|, (ia, ib) = floor((a + 1) / 2 * res) clamped,
+ *   cell = (face * res + ib) * res + ia.
+ */
+struct LightGridHeader {
+    uint32_t res, ncell;     /* ncell = 6 * res * res, cells per light */
+    uint32_t off_cells, off_gstart, off_idx, off_sph; /* word offsets from the blob's base (off_sph a multiple of 4) */
+    uint32_t nitems, pad_;
 };
 
 /* fields of an object record in DevScene::tab */
@@ -149,6 +184,8 @@ struct DevWork {
                              a pixel are independent loads for k_resolve (a linked chain through
                              the nodes cost one dependent HBM round trip per sample)   */
     uint32_t *counters;   /* counter block of this batch (layout below)                */
+    float4 *loopq;        /* the job pipeline's loop queues (rt_jobs.inc, k_loop): RT_SHARDS x loop_capS entries of 4 float4 */
+    uint32_t loop_capS;
     uint32_t cap;         /* entries per queue / node pool                             */
     uint32_t capS;        /* entries per shard = cap / RT_SHARDS                       */
 
@@ -252,7 +289,7 @@ size_t rt_scene_lds_bytes(const DevScene &S);
 void rt_launch_jobs_hits(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
                          const DevLevel0 &Z, hipStream_t stream);
 void rt_launch_jobs_trace(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
-                          const DevLevel0 &Z, uint32_t level, uint32_t expect, hipStream_t stream);
+                          const DevLevel0 &Z, uint32_t level, uint32_t expect, bool spawns, hipStream_t stream);
 void rt_launch_jobs_shadefold(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevLevel0 &Z,
                               uint32_t level, uint32_t expect, hipStream_t stream);
 void rt_launch_jobs_resolve(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
@@ -260,7 +297,7 @@ void rt_launch_jobs_resolve(const DevScene &S, const DevCamera &C, const DevWork
 void rt_launch_jobs_hits_fast(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
                               const DevLevel0 &Z, hipStream_t stream);
 void rt_launch_jobs_trace_fast(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
-                               const DevLevel0 &Z, uint32_t level, uint32_t expect, hipStream_t stream);
+                               const DevLevel0 &Z, uint32_t level, uint32_t expect, bool spawns, hipStream_t stream);
 void rt_launch_jobs_shadefold_fast(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevLevel0 &Z,
                                    uint32_t level, uint32_t expect, hipStream_t stream);
 void rt_launch_jobs_resolve_fast(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,

@@ -2898,16 +2898,29 @@ void RT_WRAP(rt_launch_jobs_hits)(const DevScene &S, const DevCamera &C, const D
     const dim3 grid((C.W + 31u) / 32u, R.ntiles);
     k_hits<<<grid, RT_BLOCK, (size_t)S.nPolySlots * sizeof(float4), stream>>>(S, C, Wk, R, Z);
 }
-/* `expect`: hits per shard the level is expected to hold (0: unknown, or level 0 - a full resident set) */
+/* `expect`: hits per shard the level is expected to hold (0: unknown, or level 0 - a full resident set).  The
+ * shadow rays of the level's hits, then (spawns: level != depth, raytrace.c:405,452) their child rays. */
 void RT_WRAP(rt_launch_jobs_trace)(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
-                                   const DevLevel0 &Z, uint32_t level, uint32_t expect, hipStream_t stream)
+                                   const DevLevel0 &Z, uint32_t level, uint32_t expect, bool spawns, hipStream_t stream)
 {
     const size_t lds = (size_t)S.nPolySlots * sizeof(float4);
-    void (*kernel)(DevScene, DevCamera, DevWork, DevRows, DevLevel0, uint32_t) = level == 0u ? k_trace<true> : k_trace<false>;
-    /* a block's four waves work through ~2 rounds of jobs at least: a sparse level gets a small grid */
-    const uint32_t jobs = expect ? (uint32_t)((uint64_t)expect * (S.nLights + 2u) / (2u * RT_BLOCK)) + 1u : 0u;
-    const uint32_t grid = queue_grid(Wk, (const void *)kernel, lds, jobs ? jobs * RT_BLOCK / 2u : 0u);
-    kernel<<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, R, Z, level);
+    for (int shadow = 1; shadow >= 0; --shadow) {
+        const uint32_t kinds = shadow ? S.nLights : (spawns ? 2u : 0u);
+        if (!kinds || (shadow && !S.lgrid))
+            continue;
+        void (*kernel)(DevScene, DevCamera, DevWork, DevRows, DevLevel0, uint32_t) =
+            level == 0u ? (shadow ? k_trace<true, true> : k_trace<true, false>)
+                        : (shadow ? k_trace<false, true> : k_trace<false, false>);
+        /* a block's four waves work through ~2 rounds of jobs at least: a sparse level gets a small grid */
+        const uint32_t slices = expect ? (uint32_t)((uint64_t)expect * kinds / (2u * RT_BLOCK)) + 1u : 0u;
+        const uint32_t grid = queue_grid(Wk, (const void *)kernel, lds, slices ? slices * RT_BLOCK / 2u : 0u);
+        kernel<<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, R, Z, level);
+        /* ... and its rays that the grids could not take (few: a small grid), before the other kind of ray re-uses
+         * the shard's loop queue */
+        void (*loop)(DevScene, DevWork, DevLevel0, uint32_t) =
+            level == 0u ? (shadow ? k_loop<true, true> : k_loop<true, false>) : (shadow ? k_loop<false, true> : k_loop<false, false>);
+        loop<<<RT_SHARDS * 8u, RT_BLOCK, 0, stream>>>(S, Wk, Z, level);
+    }
 }
 void RT_WRAP(rt_launch_jobs_shadefold)(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevLevel0 &Z,
                                        uint32_t level, uint32_t expect, hipStream_t stream)

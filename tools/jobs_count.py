@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""development: the job kernels' counters of a -DRT_JOBS_COUNT build (RT_HIP_LIB=...): per kind of ray, iterations of the
+waves' loops, walking lanes per iteration, jobs per refill, rays that took the loop over every sphere.
+usage: RT_HIP_LIB=raytracer_amd/librt_hip_b.so python tools/jobs_count.py c5s|c4"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import raytracer_amd as rt
+from bench import CONFIGS
+cfg = sys.argv[1]
+scene_args, W, H, s, d, _, _ = CONFIGS[cfg]
+sc = rt.Scene.synthetic(*scene_args)
+cam = rt.prepare_camera(sc, W, H, s, d)
+ctx = rt.Context()
+ctx.upload(sc)
+fb = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+for _ in range(2):
+    ctx.render_rows(cam, fb.data_ptr(), 0, 0, H, 0)
+    st = ctx.finish()
+for name, f in (("shadow", ("sphere_tests", "sphere_hits", "polygon_tests", "polygon_rej_parallel", "polygon_rej_behind")),
+                ("child", ("polygon_full", "polygon_hits", "lights_lit", "nodes_sphere", "nodes_polygon"))):
+    it, act, refill, jobs, loop = (getattr(st, k) for k in f)
+    print(f"{cfg} {name}: wave iterations {it:.3e}, walking lanes per iteration {act / max(it, 1):.1f}, refills {refill:.3e} "
+          f"({jobs / max(refill, 1):.1f} jobs each), jobs {jobs:.3e} ({it * 64 / max(jobs, 1):.1f} lane-iterations a job), loop rays {loop:.3e}")
+print("rays", st.primary_rays, st.shadow_rays, st.reflection_rays, st.transmission_rays, "shade nodes", st.shade_nodes)
