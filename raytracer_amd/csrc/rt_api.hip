@@ -7,6 +7,7 @@
 #include "rt_hip.h"
 #include "rt_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <mutex>
 #include <stdarg.h>
@@ -490,7 +491,9 @@ void note_levels(rt_hip_ctx *c, const uint32_t *cnt, uint32_t levels, bool first
         uint32_t nodes = 0;
         for (uint32_t l = 0; l < levels; ++l) {
             const uint64_t v = *(const uint64_t *)(cnt + CNT_LEVELS + (l * RT_SHARDS + sh) * RT_LINE_WORDS);
-            nodes += (uint32_t)v;
+            /* (the job pipeline's level-0 word counts the entries of k_hits' spawn log, which has slots of its own
+             * and as many entries as samples at most) */
+            nodes += (l == 0u && jobs_path(c, c->job.stats)) ? 0u : (uint32_t)v;
             if ((uint32_t)(v >> 32) > need)
                 need = (uint32_t)(v >> 32);
         }
@@ -1415,30 +1418,47 @@ void build_light_grids(const std::vector<float4> &sph, const std::vector<double>
     H.ncell = (uint32_t)ncell;
     H.off_cells = (uint32_t)(sizeof H / sizeof(uint32_t));
     H.off_gstart = H.off_cells + (uint32_t)count.size();
-    H.off_idx = H.off_gstart + nL + 1;
-    H.off_sph = (H.off_idx + nitems + 3u) & ~3u;
+    H.off_idx = 0; /* (items are 32-byte records now: off_sph) */
+    H.off_sph = (H.off_gstart + nL + 1 + 3u) & ~3u;
     H.nitems = nitems;
     H.pad_ = 0;
-    words.assign((size_t)H.off_sph + (size_t)nitems * 4u, 0u);
+    words.assign((size_t)H.off_sph + (size_t)nitems * 8u, 0u);
     memcpy(words.data(), &H, sizeof H);
     memcpy(words.data() + H.off_cells, count.data(), count.size() * sizeof(uint32_t));
     memcpy(words.data() + H.off_gstart, gcount.data(), gcount.size() * sizeof(uint32_t));
-    uint32_t *idx = words.data() + H.off_idx;
-    float4 *isph = (float4 *)(words.data() + H.off_sph);
+    /* an item: (centre, r*r), (bits of the sphere's index, key, -, -).  key = distance from the light at which the
+     * grown ball begins: a shadow ray that starts `mag` from the light cannot meet a sphere whose key exceeds mag,
+     * and a cell's list is sorted by key, so its scan ends there.  The global lists carry key 0. */
+    float4 *item = (float4 *)(words.data() + H.off_sph);
     std::vector<uint32_t> fill(count.begin(), count.end() - 1);
+    std::vector<float> key(n);
     for (uint32_t l = 0; l < nL; ++l) {
+        const double L[3] = {sc->lights[l].position.x, sc->lights[l].position.y, sc->lights[l].position.z};
+        const double eta = 1e-5 * (fmax(fabs(L[0]), fmax(fabs(L[1]), fabs(L[2]))) + reach + 1.0);
         uint32_t g = gcount[l];
-        for (size_t k = 0; k < n; ++k) { /* ascending k: every list comes out sorted */
+        for (size_t k = 0; k < n; ++k) {
+            const double w[3] = {sph[k].x - L[0], sph[k].y - L[1], sph[k].z - L[2]};
+            const double dist = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+            key[k] = (float)fmax(0.0, (dist - (grown[k] + eta) * 1.0001) * 0.9999 - 1e-4);
             each_cell(l, k, [&](size_t ci) {
-                idx[fill[ci]] = (uint32_t)k;
-                isph[fill[ci]] = sph[k];
+                item[2 * (size_t)fill[ci]] = sph[k];
+                item[2 * (size_t)fill[ci] + 1] = make_float4(__builtin_bit_cast(float, (uint32_t)k), key[k], 0.f, 0.f);
                 fill[ci]++;
             });
             if (global[(size_t)l * n + k]) {
-                idx[g] = (uint32_t)k;
-                isph[g] = sph[k];
+                item[2 * (size_t)g] = sph[k];
+                item[2 * (size_t)g + 1] = make_float4(__builtin_bit_cast(float, (uint32_t)k), 0.f, 0.f, 0.f);
                 ++g;
             }
+        }
+        const size_t ncell_l = ncell;
+        for (size_t ci = (size_t)l * ncell_l; ci < (size_t)(l + 1) * ncell_l; ++ci) { /* nearest the light first */
+            const uint32_t b0 = count[ci], e0 = count[ci + 1];
+            if (e0 - b0 < 2)
+                continue;
+            struct It { float4 a, b; };
+            It *first = (It *)(item + 2 * (size_t)b0);
+            std::stable_sort(first, first + (e0 - b0), [](const It &x, const It &y) { return x.b.y < y.b.y; });
         }
     }
 }

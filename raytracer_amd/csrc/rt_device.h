@@ -104,8 +104,10 @@ struct CellRec {
  * any-hit search is then ONE cell lookup and a scan of that cell's list and the global list - no walk.  Built by
  * rt_hip_scene_upload (rt_api.hip, build_light_grids); the same exclusions as the grid: direction of unit length,
  * origin within the grid's reach.
- *   words: LightGridHeader | cellStart[nLights * 6 * res * res + 1] | gstart[nLights + 1] | idx[nitems] |
- *          sph[nitems] (float4: centre, r*r).  Cell lists first, the global lists behind them.
+ *   words: LightGridHeader | cellStart[nLights * 6 * res * res + 1] | gstart[nLights + 1] | item[nitems], 32 bytes
+ *          each: (centre, r*r), (bits of the sphere's index, key, -, -); key = the distance from the light at which
+ *          the grown ball begins, a cell's list sorted by it (a ray that starts nearer the light than that cannot
+ *          meet the sphere: the scan of the cell's list ends there).  Cell lists first, the global lists behind them.
  * cell of direction u (from the light): m = axis of the largest |u|, face = 2 m + (u[m] < 0),
  *   (a, b) = the other two components in axis order / |u[m]|, (ia, ib) = floor((a + 1) / 2 * res) clamped,
  *   cell = (face * res + ib) * res + ia.
