@@ -1283,7 +1283,7 @@ void build_grid(const std::vector<float4> &sph, const rt_scene *sc, const std::v
                     }
         }
         if (pass == 1) {
-            /* ... and the cells once more as 64-byte records with their spheres inline (CellRec) */
+            /* ... and the cells once more as 128-byte records with their spheres inline (CellRec) */
             const size_t lists = G.words + cells + 1 + items.size();
             G.rec_words = (uint32_t)((lists + 3u) & ~(size_t)3u);
             G.pad_[0] = G.pad_[1] = G.pad_[2] = 0u;
@@ -1387,7 +1387,8 @@ void build_light_grids(const std::vector<float4> &sph, const std::vector<double>
                     }
             }
         }
-        if (listed <= 16.0 * (double)n * nL || res <= 8)
+        static const double budget = [] { const char *e = getenv("RT_HIP_LGRID_BUDGET"); return e && atof(e) > 0.0 ? atof(e) : 16.0; }();
+        if (listed <= budget * (double)n * nL || res <= 8) /* (development: cells listed per sphere and light at most) */
             break;
     }
     const size_t ncell = (size_t)6 * res * res;

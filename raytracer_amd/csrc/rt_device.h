@@ -83,16 +83,22 @@ struct GridHeader {
     uint32_t rec_words;  /* where the cell records start: words from the grid's base, a multiple of 4 */
     uint32_t pad_[3];
 };
-/* The same cells once more, one 64-byte record each, for the walks of the job pipeline (rt_jobs.inc): a lane gets a
- * cell's spheres with ONE round trip instead of three dependent ones (cellStart -> items -> sph).
- *   count <= 3: the cell's spheres are idx[0 .. count) / sph[0 .. count) (centre, r*r: DevScene::sph's words)
+/* The same cells once more, one 128-byte record each, for the walks of the job pipeline (rt_jobs.inc): a lane gets a
+ * cell's spheres with ONE round trip instead of three dependent ones (cellStart -> items -> sph), and every walking
+ * lane of a wave does the same thing per cell.  (Six spheres: the cells list the spheres GROWN by what the
+ * reference's test accepts beyond geometry at the grid's reach - config 5's 0.15-radius spheres count as 0.35 - so a
+ * cell holds four on average; with three inline slots four fifths of the walk's time went into the fuller cells'
+ * lists, one sphere per iteration.)
+ *   count <= 6: the cell's spheres are idx[0 .. count) / sph[0 .. count) (centre, r*r: DevScene::sph's words)
  *   else      : bit 31 set, count & 0x7fffffff entries of the grid's item list from idx[0] on */
+#define RT_CELL_INLINE 6u
 struct CellRec {
     uint32_t count;
-    uint32_t idx[3];
-    float4 sph[3];
+    uint32_t idx[RT_CELL_INLINE];
+    uint32_t pad_;
+    float4 sph[RT_CELL_INLINE];
 };
-#define RT_CELL_INLINE 3u
+static_assert(sizeof(CellRec) == 128, "cell records are two cache-line halves");
 #define RT_CELL_LISTED 0x80000000u
 
 /*

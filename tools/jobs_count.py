@@ -22,4 +22,9 @@ for name, f in (("shadow", ("sphere_tests", "sphere_hits", "polygon_tests", "pol
     it, act, refill, jobs, loop = (getattr(st, k) for k in f)
     print(f"{cfg} {name}: wave iterations {it:.3e}, walking lanes per iteration {act / max(it, 1):.1f}, refills {refill:.3e} "
           f"({jobs / max(refill, 1):.1f} jobs each), jobs {jobs:.3e} ({it * 64 / max(jobs, 1):.1f} lane-iterations a job), loop rays {loop:.3e}")
+for name, f in (("shadow", ("k0_sphere_tests", "k0_sphere_hits", "k0_polygon_tests", "k0_polygon_rej_parallel")),
+                ("child", ("k0_polygon_rej_behind", "k0_polygon_full", "k0_lights_lit", "k0_nodes_sphere"))):
+    blocks, lanes, listed, tests = (getattr(st, k) for k in f)
+    print(f"{cfg} {name}: sphere tests {tests:.3e} (lane level), distance blocks run {blocks:.3e} with {lanes / max(blocks, 1):.1f} lanes each, "
+          f"lane-iterations in a listed cell {listed:.3e}")
 print("rays", st.primary_rays, st.shadow_rays, st.reflection_rays, st.transmission_rays, "shade nodes", st.shade_nodes)
