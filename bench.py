@@ -167,12 +167,10 @@ def main():
                     help="HIP stream priority of the shared render stream (k_primary and the wide bounce levels); the tail "
                          "stream has the normal one.  high: the tail of frame i fills what k_primary of frame i+1 leaves "
                          "(0.225 ms per frame, k_primary 0.114 ms with three frames in flight); normal: the two share alike (0.212 ms, 0.124 ms)")
-    ap.add_argument("--launch-plan", choices=["on", "off", "pairs"], default="on",
+    ap.add_argument("--launch-plan", choices=["on", "off"], default="on",
                     help="k_primary's launch plan (rt_hip_ctx_set_launch_plan): each context times the tiles of its first "
                          "frame and launches the blocks of the next ones slowest first; off: raster order, top-down "
-                         "(k_primary alone 0.099 against 0.124 ms, 0.106 against 0.125 ms in the pipelined run); pairs: and the slow "
-                         "blocks of launches that do not fill the GPU as pairs (mode 2: a rank's eighth of config 3, "
-                         "k_primary 0.062 against 0.094 ms, but the frame loop there is bound by the host: 0.166 against 0.153 ms)")
+                         "(k_primary alone 0.099 against 0.124 ms, 0.106 against 0.125 ms in the pipelined run)")
     ap.add_argument("--shared-stream", action="store_true",
                     help="with more than one rank, or a workload other than config 2: the arrangement of config 2 on one GPU (frames "
                          "on ONE render stream + a tail stream, three in flight) instead of --overlap with six in flight.  A rank's share of a frame spread over N GPUs "
@@ -250,7 +248,7 @@ def main():
         c = rt.Context(device=local_rank)  # queue capacity sized by the first render of this rank's share
         c.upload(scene)
         c.set_numerics(numerics)
-        c.set_launch_plan({"off": 0, "on": 1, "pairs": 2}[args.launch_plan])
+        c.set_launch_plan(args.launch_plan == "on")
         if tail is not None:
             c.set_tail_stream(tail.cuda_stream)
         ctxs.append(c)

@@ -157,7 +157,7 @@ typedef struct {
     /* k_primary launches of this render that followed a launch plan, and plans built at its end
      * (rt_hip_ctx_set_launch_plan) */
     uint32_t planned_launches, plan_builds;
-    uint32_t plan_pairs;        /* blocks the plan built at the end of this render launches as pairs */
+    uint32_t reserved2_;
     uint32_t reserved_;
 } rt_hip_stats;
 
@@ -332,6 +332,16 @@ int  rt_hip_ctx_set_numerics(rt_hip_ctx *ctx, int mode);
  * frames are strictly sequential, main.c:159-165).  Pixels and counters are unchanged. */
 int  rt_hip_ctx_set_tail_stream(rt_hip_ctx *ctx, void *stream);
 
+/* Which kernels render big scenes (more than 128 spheres; the reference has one loop over all objects for every
+ * ray, raytrace.c:188-272).  RT_PIPELINE_AUTO (the default): the job pipeline - rays as jobs of persistent lanes,
+ * shadow rays through per-light direction grids, child rays over a sphere grid (csrc/rt_jobs.inc).
+ * RT_PIPELINE_FUSED: the fused primary / bounce kernels that render small scenes, walking the sphere grid per lane
+ * (2-3x slower there; what instrumented and phong-blinn renders always use).  Same pixels, bit for bit, in the
+ * exact build.  No counterpart in the reference.  Returns 0 or RT_E_INVALID. */
+#define RT_PIPELINE_AUTO  0
+#define RT_PIPELINE_FUSED 1
+int  rt_hip_ctx_set_pipeline(rt_hip_ctx *ctx, int mode);
+
 /* Kernels compiled for the scene shape the reference's parse_scene always returns (2 spheres, 1 quad, 1
  * light: every count a compile-time constant) are used when the uploaded scene has that shape; enable = 0
  * makes the context use the generic kernels for every scene (same pixels; what any other scene gets).
@@ -344,14 +354,8 @@ void rt_hip_ctx_set_specialization(rt_hip_ctx *ctx, int enable);
  * late and run long (reference scene, 1080p 16 spp: 0.124 -> 0.099 ms).  The plan is a permutation of the blocks -
  * pixels and ray counters do not depend on it - built once per view (camera, rows, scene) at the end of the
  * recording render (rt_hip_finish: one 4-byte-per-wave copy to the host, a counting sort, one copy back) and
- * refreshed every 8th render while the view keeps changing.
- * mode 2: as 1, and a launch whose slow tiles (over 20 us) leave half of the GPU's wave slots free - it is as long
- * as its slowest tile whatever the order - lists the blocks of those tiles TWICE: the two blocks share the samples
- * of the tiles (the second block's finished samples wait as colours beside the pixel's root ids and are added in
- * the reference's order by the resolve kernel: same pixels).  A rank's eighth of a 4K frame: 0.094 -> 0.062 ms for
- * the kernel; worth it where the launch's latency counts (one small frame at a time), not in a frame loop that is
- * bound by the host.  mode 3: every block a pair (tests).
- * No counterpart in the reference (its pixels are one serial loop, raytrace.c:746-792). */
+ * refreshed every 8th render while the view keeps changing.  Big scenes (RT_PIPELINE_AUTO below) have no such
+ * kernel and no plan.  No counterpart in the reference (its pixels are one serial loop, raytrace.c:746-792). */
 void rt_hip_ctx_set_launch_plan(rt_hip_ctx *ctx, int mode);
 
 /* The host half of the launch plan, exported for tests (no GPU involved): the order rt_hip_finish builds from

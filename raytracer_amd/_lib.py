@@ -18,6 +18,7 @@ EXPORTS = [
     "rt_write_image", "write_image", "rt_hip_selftest_arith", "rt_load_scene", "rt_hip_deinterleave",
     "rt_hip_render_devices", "rt_hip_tone", "rt_hip_tone_sums", "rt_hip_tone_apply", "rt_hip_selftest_grid",
     "rt_hip_tone_static", "rt_hip_ctx_set_numerics", "rt_hip_ctx_set_specialization", "rt_hip_ctx_set_launch_plan", "rt_launch_plan_order",
+    "rt_hip_ctx_set_pipeline",
 ]
 
 _lib = None
@@ -96,6 +97,8 @@ def load():
     lib.rt_hip_ctx_set_specialization.restype = None
     lib.rt_hip_ctx_set_launch_plan.argtypes = [vp, i32]
     lib.rt_hip_ctx_set_launch_plan.restype = None
+    lib.rt_hip_ctx_set_pipeline.argtypes = [vp, i32]
+    lib.rt_hip_ctx_set_pipeline.restype = i32
     lib.rt_launch_plan_order.argtypes = [vp, u32, u32, vp]
     lib.rt_launch_plan_order.restype = None
     lib.rt_hip_ctx_set_tail_stream.argtypes = [vp, vp]

@@ -120,6 +120,7 @@ def render(scene, cam, row0=0, nrows=None, want_radiance=True, devices=None):
 TONE_WARD, TONE_REINHARD = 1, 2
 SHADE_PHONG, SHADE_PHONGBLINN = 0, 1
 NUMERICS_EXACT, NUMERICS_FAST = 0, 1
+PIPELINE_AUTO, PIPELINE_FUSED = 0, 1
 
 
 def tone(d_radiance, d_argb, npixels, op, ld_max, l_max, key_pixel=-1, stream=0):
@@ -174,9 +175,14 @@ class Context:
         check(load().rt_hip_ctx_set_numerics(self._h, int(mode)), "rt_hip_ctx_set_numerics")
 
     def set_launch_plan(self, on):
-        """False / 0: k_primary's blocks always in raster order; True / 1 (the default): slowest first; 2: ... and the
-        slow blocks of small launches as pairs; 3: every block a pair (tests) (rt_hip_ctx_set_launch_plan)"""
-        load().rt_hip_ctx_set_launch_plan(self._h, int(on))
+        """False: k_primary's blocks always in raster order; True (the default): slowest first, from the times the
+        tiles of the last frame of this shape took (rt_hip_ctx_set_launch_plan)"""
+        load().rt_hip_ctx_set_launch_plan(self._h, int(bool(on)))
+
+    def set_pipeline(self, mode):
+        """PIPELINE_AUTO (big scenes through the job pipeline, csrc/rt_jobs.inc) or PIPELINE_FUSED (every scene through
+        the fused primary / bounce kernels) - rt_hip_ctx_set_pipeline"""
+        check(load().rt_hip_ctx_set_pipeline(self._h, int(mode)), "rt_hip_ctx_set_pipeline")
 
     def set_specialization(self, on):
         """False: generic kernels also for the reference's scene shape (rt_hip_ctx_set_specialization)"""

@@ -100,6 +100,7 @@ struct rt_hip_ctx {
     /* options */
     bool timing = false;
     bool no_shape = false; /* generic kernels only (survives scene uploads) */
+    bool no_jobs = false;  /* big scenes through the fused kernels too (rt_hip_ctx_set_pipeline) */
     int shading = RT_SHADE_PHONG;
     int numerics = RT_NUMERICS_EXACT;
     bool auto_cap = false;  /* capacity follows the jobs (rt_hip_ctx_create with 0 entries) */
@@ -132,12 +133,8 @@ struct rt_hip_ctx {
      * The plan is built once per view (camera, rows, scene); while the view keeps changing the last plan is
      * used as it is and rebuilt every kPlanRefresh frames.
      */
-    int launch_plan = 1;           /* rt_hip_ctx_set_launch_plan: 0 off, 1 order, 2 order + pairs in small launches,
-                                      3 order + every block a pair (tests) */
-    uint32_t plan_len = 0;         /* entries of d_plan: the blocks, the paired ones twice */
-    std::vector<uint8_t> plan_paired; /* per block of the raster: launched as a pair by d_plan */
-    float4 *leaf2 = nullptr;       /* DevRows::leaf2, allocated when a plan first has pairs */
-    size_t leaf2_cap = 0;
+    int launch_plan = 1;           /* rt_hip_ctx_set_launch_plan: 0 off, 1 blocks slowest first */
+    uint32_t plan_len = 0;         /* entries of d_plan: the blocks */
     uint32_t *d_plan = nullptr, *d_wave_ticks = nullptr;
     size_t plan_cap = 0;           /* blocks both arrays hold */
     bool plan_valid = false;       /* d_plan holds an order for plan_nbx x plan_ntiles blocks */
@@ -148,7 +145,6 @@ struct rt_hip_ctx {
     uint64_t scene_serial = 0;     /* counts the uploads that changed the scene */
 };
 constexpr uint32_t kPlanRefresh = 8;
-constexpr uint32_t kPlanPairTicks = 2000; /* 20 us: a block with a slower wave may become a pair (rebuild_plan) */
 
 namespace {
 
@@ -221,7 +217,7 @@ int ensure_pix(rt_hip_ctx *c, size_t npix, size_t spp2)
 bool jobs_path(const rt_hip_ctx *c, bool stats)
 {
     static const bool off = getenv("RT_HIP_NO_JOBS") != nullptr; /* development: the fused kernels for every scene */
-    return !off && c->S.grid != nullptr && (c->S.lgrid != nullptr || c->S.nLights == 0u) && !stats && c->shading == RT_SHADE_PHONG &&
+    return !off && !c->no_jobs && c->S.grid != nullptr && (c->S.lgrid != nullptr || c->S.nLights == 0u) && !stats && c->shading == RT_SHADE_PHONG &&
            c->S.nLights <= RT_JOBS_MAX_LIGHTS;
 }
 
@@ -271,11 +267,6 @@ DevRows rows_of(const rt_hip_ctx *c, const Batch &b)
     R.argb = c->d_argb;
     R.radiance = c->d_rad;
     R.tile_done = c->tile_done;
-    {
-        const size_t rows = (size_t)c->C.sqrtSpp * c->C.sqrtSpp - (size_t)(c->C.sqrtSpp / 2u) * c->C.sqrtSpp;
-        if (c->leaf2 && rows * R.ntiles * 8u * c->C.W <= c->leaf2_cap)
-            R.leaf2 = c->leaf2;
-    }
     if (b.t0 == 0 && b.t1 == j.ntiles) { /* the whole job in one batch: what a launch plan is for */
         if (c->plan_use) {
             R.plan = c->d_plan;
@@ -595,62 +586,9 @@ int rebuild_plan(rt_hip_ctx *c)
     std::vector<uint32_t> ticks(blocks * (RT_BLOCK / 64u));
     HIP_TRY(hipMemcpyAsync(ticks.data(), c->d_wave_ticks, ticks.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    constexpr uint32_t waves = RT_BLOCK / 64u;
-    /* (of a pair only the first block's waves record their time: half the block's) */
-    for (size_t b = 0; b < blocks && b < c->plan_paired.size(); ++b)
-        if (c->plan_paired[b] && c->plan_use)
-            for (uint32_t w = 0; w < waves; ++w)
-                ticks[b * waves + w] *= 2u;
-    std::vector<uint32_t> order(blocks);
-    rt_launch_plan_order(ticks.data(), nbx, ntiles, order.data());
-    /* Pairs.  A launch that fills the GPU several times over is bound by what the GPU can issue, and the launch
-     * order is all that can be done for it (the reference's scene at 1080p x 16 on one GPU: 7 900 waves of over 20 us
-     * for 7 168 wave slots - and a pair costs: the second block's samples all become roots, more nodes, a longer
-     * k_resolve).  A launch whose slow waves leave half the slots free is as long as its slowest wave, 60-90 us for a
-     * tile of the glass sphere however small the launch (a rank's eighth of the 4K frame: 4 000 such waves): there
-     * every block with a wave over 20 us is launched as two blocks that share its tiles' samples - if the host
-     * asked for it (mode 2): k_primary of that eighth takes 0.062 instead of 0.094 ms, but the frame loop of a
-     * multi-GPU host is bound by the host (120 us to submit a frame and its gather), not by this kernel. */
-    int cus = 256;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
-    const uint64_t slots = (uint64_t)cus * 28u; /* 7 blocks of 4 waves per CU */
-    uint64_t slow = 0;
-    for (uint32_t t : ticks)
-        slow += t > kPlanPairTicks ? 1u : 0u;
-    const bool underfilled = 2u * slow * 4u <= slots * 5u; /* twice the slow waves still fit 1.25 x the slots */
-    const double limit = c->launch_plan == 3 ? -1.0 : (c->launch_plan == 2 && underfilled) ? (double)kPlanPairTicks : 4.0e9;
-    c->plan_paired.assign(blocks, 0);
-    std::vector<uint32_t> plan;
-    plan.reserve(2 * blocks);
-    uint32_t pairs = 0;
-    for (size_t i = 0; i < blocks; ++i) {
-        const uint32_t e = order[i], b = ((e >> 15) & 0x7fffu) * nbx + (e & 0x7fffu);
-        uint32_t cost = 0;
-        for (uint32_t w = 0; w < waves; ++w)
-            cost = ticks[b * waves + w] > cost ? ticks[b * waves + w] : cost;
-        if ((double)cost > limit && (c->C.sqrtSpp & 1u) == 0u) {
-            plan.push_back(e | RT_PLAN_PAIRED);
-            plan.push_back(e | RT_PLAN_PAIRED | RT_PLAN_SECOND);
-            c->plan_paired[b] = 1;
-            ++pairs;
-        } else {
-            plan.push_back(e);
-        }
-    }
+    std::vector<uint32_t> plan(blocks);
+    rt_launch_plan_order(ticks.data(), nbx, ntiles, plan.data());
     c->plan_len = (uint32_t)plan.size();
-    c->stats.plan_pairs = pairs;
-    if (pairs) { /* room for the finished colours of the second waves */
-        const size_t need = ((size_t)c->C.sqrtSpp * c->C.sqrtSpp - (size_t)(c->C.sqrtSpp / 2u) * c->C.sqrtSpp) *
-                            (size_t)ntiles * 8u * c->C.W;
-        if (need > c->leaf2_cap) {
-            if (c->leaf2)
-                HIP_TRY(hipFree(c->leaf2));
-            c->leaf2 = nullptr;
-            c->leaf2_cap = 0;
-            HIP_TRY(hipMalloc((void **)&c->leaf2, need * sizeof(float4)));
-            c->leaf2_cap = need;
-        }
-    }
     HIP_TRY(hipMemcpyAsync(c->d_plan, plan.data(), plan.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream)); /* (plan[] is this function's) */
     c->plan_valid = true;
@@ -986,7 +924,6 @@ void rt_hip_ctx_destroy(rt_hip_ctx *c)
     if (c->work_blob) (void)hipFree(c->work_blob);
     if (c->pixAcc) (void)hipFree(c->pixAcc);
     if (c->tile_done) (void)hipFree(c->tile_done);
-    if (c->leaf2) (void)hipFree(c->leaf2);
     if (c->roots) (void)hipFree(c->roots);
     if (c->loopq) (void)hipFree(c->loopq);
     if (c->Z.hit) (void)hipFree(c->Z.hit);
@@ -1008,12 +945,29 @@ void rt_hip_ctx_set_specialization(rt_hip_ctx *c, int enable)
     }
 }
 
+int rt_hip_ctx_set_pipeline(rt_hip_ctx *c, int mode)
+{
+    if (!c || (mode != RT_PIPELINE_AUTO && mode != RT_PIPELINE_FUSED)) {
+        set_err("pipeline %d is neither RT_PIPELINE_AUTO nor RT_PIPELINE_FUSED", mode);
+        return RT_E_INVALID;
+    }
+    if (c->pending) { /* the render in flight was planned for the other pipeline */
+        const int rc = rt_hip_finish(c, nullptr);
+        if (rc)
+            return rc;
+    }
+    if (c->no_jobs != (mode == RT_PIPELINE_FUSED))
+        c->seen_valid = false; /* (the two pipelines count their tree nodes differently) */
+    c->no_jobs = mode == RT_PIPELINE_FUSED;
+    return 0;
+}
+
 void rt_hip_ctx_set_launch_plan(rt_hip_ctx *c, int enable)
 {
     if (c) {
-        if (c->launch_plan != enable)
+        if (c->launch_plan != (enable != 0 ? 1 : 0))
             c->plan_valid = false;
-        c->launch_plan = enable < 0 ? 0 : enable > 3 ? 1 : enable;
+        c->launch_plan = enable != 0 ? 1 : 0;
     }
 }
 
@@ -1641,7 +1595,7 @@ static int plan_frame(rt_hip_ctx *c, bool one_batch)
         c->d_plan = c->d_wave_ticks = nullptr;
         c->plan_cap = 0;
         c->plan_valid = false;
-        HIP_TRY(hipMalloc((void **)&c->d_plan, 2u * blocks * sizeof(uint32_t))); /* (every block may be a pair) */
+        HIP_TRY(hipMalloc((void **)&c->d_plan, blocks * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void **)&c->d_wave_ticks, blocks * (RT_BLOCK / 64u) * sizeof(uint32_t)));
         c->plan_cap = blocks;
     }

@@ -142,15 +142,11 @@ enum {
  *   contiguous slab [row0,row0+n): y_first = out_first = row0 + 8*t0, y_step = 8, y_limit = row0+n
  *   cyclic 8-row blocks (phase r of N ranks, multi-GPU): y_first = (t0*N + r)*8, y_step = 8*N,
  *   y_limit = H, out_first = 8*t0 (rows of the rank's compact local buffer)               */
-#define RT_PLAN_PAIRED 0x40000000u
-#define RT_PLAN_SECOND 0x80000000u
-#define RT_ROOTS_SPLIT 0x80000000u /* bit of pixAcc.w: the second half of the pixel's samples are all roots (k_primary) */
 struct DevRows {
     uint32_t y_first, y_step, y_limit, out_first, ntiles;
     /* k_primary's launch order (rt_api.hip, "launch plan"): block b of a 1-D grid of plan_len blocks renders block
-     * column plan[b] & 0x7fff of tile row (plan[b] >> 15) & 0x7fff.  Every block of the raster is listed once, or
-     * twice in a row with RT_PLAN_PAIRED set, the second time with RT_PLAN_SECOND as well (the two blocks then
-     * share the tiles' samples) - so any plan renders the same frame.  nullptr: the raster itself, top-down. */
+     * column plan[b] & 0x7fff of tile row (plan[b] >> 15) & 0x7fff.  Every block of the raster is listed once - so
+     * any plan renders the same frame.  nullptr: the raster itself, top-down. */
     const uint32_t *plan = nullptr;
     uint32_t plan_len = 0;
     /* where every wave of k_primary leaves the time it took, in 10 ns ticks of the wall clock:
@@ -163,11 +159,7 @@ struct DevRows {
     uint32_t *argb = nullptr;
     float *radiance = nullptr;
     uint8_t *tile_done = nullptr;
-    /* [spp^2 - (sqrtSpp / 2) * sqrtSpp][pixels of the batch]: colours of the finished samples of the second waves
-     * of pairs, whose root id is RT_LEAF_ROOT (nullptr: they become childless root nodes) */
-    float4 *leaf2 = nullptr;
 };
-#define RT_LEAF_ROOT 0xFFFFFFFEu
 
 /* Per-batch work state in HBM. */
 struct DevWork {

@@ -1821,25 +1821,19 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
     /* Which block of the batch this is: the raster top-down, or - once the context has timed a frame of this
      * shape - the launch plan's order, slowest blocks first (rt_api.hip: the launch is as long as the waves
      * that start last and run longest; the raster started the floor's edge and shadow tiles at 80 us of 122). */
-    /* A plan may list a block TWICE, side by side (a pair: RT_PLAN_PAIRED, second copy RT_PLAN_SECOND): the two
-     * blocks share every tile's sample rows - where the whole launch is no longer than its longest wave (a rank's
-     * share of a frame spread over eight GPUs: 4 000 blocks, the tiles of the glass sphere 90 us each). */
-    uint32_t bx = blockIdx.x, ty = blockIdx.y, half = 0;
-    bool paired = false;
+    uint32_t bx = blockIdx.x, ty = blockIdx.y;
     const uint32_t nbx = (C.W + 31u) / 32u;
     if (R.plan) { /* (a 1-D grid of plan_len blocks) */
         const uint32_t e = const_load1(R.plan + blockIdx.x);
         bx = e & 0x7fffu;
         ty = (e >> 15) & 0x7fffu;
-        paired = (e & RT_PLAN_PAIRED) != 0u;
-        half = e >> 31;
     }
     const unsigned long long wave_t0 = R.wave_ticks ? wall_clock64() : 0ull;
-    auto wave_done = [&]() { /* (every exit of the kernel; of a pair the first block's waves: the host doubles them) */
-        if (R.wave_ticks && lane == 0u && half == 0u)
+    auto wave_done = [&]() { /* (every exit of the kernel) */
+        if (R.wave_ticks && lane == 0u)
             R.wave_ticks[(ty * nbx + bx) * (RT_BLOCK / 64u) + wv] = (uint32_t)(wall_clock64() - wave_t0);
     };
-    /* the wave's tile has no roots: its pixels are final (wave-uniform; DevRows::tile_done; first block of a pair only) */
+    /* the wave's tile has no roots: its pixels are final (wave-uniform; DevRows::tile_done) */
     auto tile_is_final = [&](bool final) {
         if (R.tile_done && lane == 0u)
             R.tile_done[(ty * nbx + bx) * (RT_BLOCK / 64u) + wv] = final ? 1u : 0u;
@@ -1854,7 +1848,7 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
     const float fv0 = ((C.hfbH - (float)y) / C.hfbH) * C.halfH;
 
     /* every wave feeds its own shard: even a single tile row spreads over all of them */
-    const uint32_t shard = ((ty * nbx + bx) * (RT_BLOCK / 64u) + half * 2u +
+    const uint32_t shard = ((ty * nbx + bx) * (RT_BLOCK / 64u) +
                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) % RT_SHARDS;
     const uint32_t node_base = shard * Wk.capS; /* level 0 opens every shard's node range */
 
@@ -1893,8 +1887,6 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
         }
         uint64_t *const stats = (uint64_t *)(Wk.counters + CNT_STATS + shard * CNT_STATS_STRIDE);
         if (__all(nothing)) { /* wave-uniform */
-            if (half != 0u)
-                return true; /* the first block of the pair finishes such a tile */
             for (uint32_t k = 0; k < C.sqrtSpp * C.sqrtSpp; ++k) {
                 accr = accr + src.kc(KC_BG + 0);
                 accg = accg + src.kc(KC_BG + 1);
@@ -1919,8 +1911,6 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
                 const float4 mC = src.tab(prec + RT_OBJ_PHONG);
                 const bool spawns = __builtin_amdgcn_readfirstlane((int)((mC.z != 0.0f || mC.w != 0.0f) && C.depth != 0u)) != 0;
                 if (!spawns) { /* raytrace.c:405,452 */
-                    if (half != 0u)
-                        return true;
                     lit_polygon_tile(S, C, src, tile_polygon, prec, fu0, fv0, accr, accg, accb);
                     if (tile_is_final(true)) {
                         if (valid)
@@ -1978,17 +1968,7 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
             return; /* wave-uniform; no barrier follows */
     }
 
-    /* A tile launched as a pair and not finished above: the first wave takes the first half of the sample rows,
-     * the second the rest - as roots all of them, from slot (sqrtSpp / 2) * sqrtSpp on: it cannot know what the
-     * first wave's samples became, and k_resolve adds a pixel's samples in the reference's order (raytrace.c:774),
-     * the first wave's sum and roots, then these.  An odd number of sample rows: the first wave takes them all. */
-    const bool split = paired && (C.sqrtSpp & 1u) == 0u;
-    if (half != 0u && !split)
-        return;
-    const uint32_t j_first = split && half ? C.sqrtSpp / 2u : 0u, j_end = split && !half ? C.sqrtSpp / 2u : C.sqrtSpp;
-    if (split && half)
-        nroots = (C.sqrtSpp / 2u) * C.sqrtSpp;
-    for (uint32_t j = j_first; j < j_end; ++j) {
+    for (uint32_t j = 0; j < C.sqrtSpp; ++j) {
         for (uint32_t i = 0; i < C.sqrtSpp; ++i) {
             float px, py, pz;
             uint32_t obj;
@@ -2030,24 +2010,14 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
              * not commute: a finished sample that FOLLOWS a root of its pixel must be added after
              * that root, so it becomes a childless root itself (silhouette pixels only: rare). */
             if (valid && !deferred && nroots != 0u) {
-                if (split && half && R.leaf2) {
-                    /* the second wave of a pair, whose samples are all roots: the finished ones leave their colour
-                     * beside the root ids (a coalesced 16-byte store; a node costs a reservation, 24 bytes here
-                     * and a 56-byte gather in k_resolve - with nodes the pairs cost k_resolve what they saved here) */
-                    R.leaf2[(size_t)(nroots - (C.sqrtSpp / 2u) * C.sqrtSpp) * pix_stride + pix] =
-                        make_float4(leaf[0], leaf[1], leaf[2], 0.0f);
-                    node = RT_LEAF_ROOT;
+                uint32_t local, no_r, no_t;
+                wave_reserve(level_line(Wk.counters, 0u, shard), false, false, Wk.capS, Wk.capS,
+                             &Wk.counters[CNT_OVERFLOW], local, no_r, no_t);
+                if (local != RT_NONE) {
+                    node = node_base + local;
+                    Wk.nodeA()[node] = make_float4(leaf[0], leaf[1], leaf[2], 0.0f);
+                    Wk.nodeK()[node] = make_float2(0.0f, __uint_as_float(RT_LINK_NONE << 3));
                     deferred = true;
-                } else {
-                    uint32_t local, no_r, no_t;
-                    wave_reserve(level_line(Wk.counters, 0u, shard), false, false, Wk.capS, Wk.capS,
-                                 &Wk.counters[CNT_OVERFLOW], local, no_r, no_t);
-                    if (local != RT_NONE) {
-                        node = node_base + local;
-                        Wk.nodeA()[node] = make_float4(leaf[0], leaf[1], leaf[2], 0.0f);
-                        Wk.nodeK()[node] = make_float2(0.0f, __uint_as_float(RT_LINK_NONE << 3));
-                        deferred = true;
-                    }
                 }
             }
             if (deferred) {
@@ -2061,13 +2031,11 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
             pc.mark(7);
         }
     }
-    if (split && half) {
-        /* (the second wave of a pair leaves roots only) */
-    } else if (tile_is_final(!split && __all(!valid || nroots == 0u))) {
+    if (tile_is_final(__all(!valid || nroots == 0u))) {
         if (valid)
             store_pixel(C, R, pix, accr, accg, accb, R.argb, R.radiance);
     } else if (valid) {
-        Wk.pixAcc[pix] = make_float4(accr, accg, accb, __uint_as_float(nroots | (split ? RT_ROOTS_SPLIT : 0u)));
+        Wk.pixAcc[pix] = make_float4(accr, accg, accb, __uint_as_float(nroots));
     }
 
     uint64_t *st = (uint64_t *)(Wk.counters + CNT_STATS + shard * CNT_STATS_STRIDE);
@@ -2461,10 +2429,6 @@ __global__ __launch_bounds__(RT_BLOCK * RT_DEEP_SUB) void k_fold_deep(DevWork Wk
 #ifndef RT_RESOLVE_GRID
 #define RT_RESOLVE_GRID 4096u
 #endif
-/* PAIRS: the launch plan of this batch has pairs (DevRows::plan): pixels of shared tiles have their roots in two
- * runs, the second possibly with finished colours in place of nodes.  A kernel of its own: that path costs 32
- * registers, and the plain kernel, which every other frame runs, would pay for them with a third of its waves. */
-template <bool PAIRS>
 __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DevCamera C, DevWork Wk, DevRows R,
                                                       uint32_t *argb, float *radiance)
 {
@@ -2486,13 +2450,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DevCamera C, DevWork Wk, D
         const size_t p = (size_t)row * C.W + x;
         const float4 acc = Wk.pixAcc[p];
         float r = acc.x, g = acc.y, b = acc.z;
-        /* roots of the pixel, in sample order: slots 0 .. n-1, and - a tile two waves of k_primary shared - the whole
-         * second half of its samples behind them, from slot (sqrtSpp / 2) * sqrtSpp on */
-        const uint32_t word = __float_as_uint(acc.w), n_first = word & ~RT_ROOTS_SPLIT;
-        const uint32_t second = (C.sqrtSpp / 2u) * C.sqrtSpp;
-        const bool split = PAIRS && (word & RT_ROOTS_SPLIT) != 0u;
-        const uint32_t nroots = split ? n_first + (C.sqrtSpp * C.sqrtSpp - second) : n_first;
-        const uint32_t skip = split ? second - n_first : 0u; /* slots between the two runs of roots */
+        const uint32_t nroots = __float_as_uint(acc.w); /* roots of the pixel, in sample order: slots 0 .. n-1 */
         /* sixteen root ids at a time (one round trip for a whole 4x4-sample pixel), then their node
          * words four roots at a time, all loads of a step independent; the sums in root order */
         for (uint32_t k0 = 0; k0 < nroots; k0 += 16u) {
@@ -2500,7 +2458,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DevCamera C, DevWork Wk, D
 #pragma unroll
             for (uint32_t u = 0; u < 16u; ++u) {
                 const uint32_t k = min(k0 + u, nroots - 1u);
-                id[u] = Wk.roots[(size_t)(k + (k >= n_first ? skip : 0u)) * npix + p];
+                id[u] = Wk.roots[(size_t)k * npix + p];
             }
 #pragma unroll
             for (uint32_t g4 = 0; g4 < 16u; g4 += 4u) {
@@ -2513,19 +2471,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DevCamera C, DevWork Wk, D
                     const uint32_t j = id[g4 + u] < Wk.cap ? id[g4 + u] : 0u;
                     A[u] = Wk.nodeA()[j]; K[u] = Wk.nodeK()[j]; cr[u] = Wk.childR()[j]; ct[u] = Wk.childT()[j];
                 }
-                if (PAIRS && split && R.leaf2) { /* (wave-uniform: a tile is shared or not) finished samples of the second wave */
-#pragma unroll
-                    for (uint32_t u = 0; u < 4u; ++u) {
-                        const uint32_t k = min(k0 + g4 + u, nroots - 1u);
-                        if (id[g4 + u] == RT_LEAF_ROOT && k >= n_first)
-                            A[u] = R.leaf2[(size_t)(k - n_first) * npix + p];
-                    }
-                }
 #pragma unroll
                 for (uint32_t u = 0; u < 4u; ++u) {
-                    if (PAIRS && k0 + g4 + u < nroots && id[g4 + u] == RT_LEAF_ROOT) {
-                        r = r + A[u].x; g = g + A[u].y; b = b + A[u].z; /* a finished colour, clamped where it was made */
-                    } else if (k0 + g4 + u < nroots && id[g4 + u] < Wk.cap) {
+                    if (k0 + g4 + u < nroots && id[g4 + u] < Wk.cap) {
                         float c[3];
                         fold_values(A[u], K[u], cr[u], ct[u], c);
                         r = r + c[0]; g = g + c[1]; b = b + c[2];
@@ -2834,11 +2782,7 @@ void rt_launch_resolve(const DevCamera &C, const DevWork &Wk, const DevRows &R, 
         grid = RT_RESOLVE_GRID;
     if (grid == 0)
         grid = 1;
-    const bool pairs = R.plan && R.plan_len > (uint32_t)((C.W + 31u) / 32u) * R.ntiles;
-    if (pairs)
-        k_resolve<true><<<(uint32_t)grid, RT_BLOCK, 0, stream>>>(C, Wk, R, d_argb, d_radiance);
-    else
-        k_resolve<false><<<(uint32_t)grid, RT_BLOCK, 0, stream>>>(C, Wk, R, d_argb, d_radiance);
+    k_resolve<<<(uint32_t)grid, RT_BLOCK, 0, stream>>>(C, Wk, R, d_argb, d_radiance);
 }
 
 void rt_launch_selftest_arith(const float *a, const float *b, const float *c, uint32_t n, float *out,
