@@ -53,7 +53,18 @@ import raytracer_amd as rt  # noqa: E402
 from raytracer_amd.dist import FramePipeline, RowPlan  # noqa: E402
 
 PEAK_FP32_TFLOPS = 157.3  # MI355X vector FP32 peak, MI355X_MICROARCH.md "Chip-level parameters"
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
+KERNEL_SOURCES = ["rt_kernels.hip", "rt_jobs.inc", "rt_arith.h", "rt_device.h", "rt_dev.h"]
+
+
+def kernels_sha():
+    """what the counters of PMC_FILE are stamped with: a hash of the kernel sources they were collected on"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "raytracer_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 # name -> (scene, W, H, sqrtSpp, depth, default steps, default warmup); scene None = the reference's hard-coded one,
 # else rt_scene_synthetic's arguments (seed, spheres, quads, lights, kind) - SURVEY.md section 8d
@@ -96,6 +107,8 @@ def pmc_for(workload_key, numerics):
         t = json.load(open(PMC_FILE))
     except (OSError, ValueError):
         return None
+    if t.get("kernels_sha") != kernels_sha():
+        return None  # counters of other kernels than the ones timed here: not reported
     return t.get(f"{workload_key}:{numerics}")
 
 
@@ -187,9 +200,11 @@ def main():
                     help="N > 1: run the all-gather + de-interleave on a second stream behind events, so that they "
                          "overlap the next frame's render (default), or on the render stream (the frames then wait "
                          "for their gathers: step = render + collective)")
-    ap.add_argument("--numerics", choices=["fast", "exact"], default="fast",
-                    help="fast (default): the tolerance build of the trace kernels (FMA, 1-ulp rcp / rsq / sqrt; pixels "
-                         "within the north star's +-1 LSB / 1e-4 on the reference's scene); exact: every operation "
+    ap.add_argument("--numerics", choices=["fast", "exact"], default=None,
+                    help="fast (the default on the reference's scene, c1-c3): the tolerance build of the trace kernels (FMA, "
+                         "1-ulp rcp / rsq / sqrt; pixels within the north star's +-1 LSB / 1e-4 there); exact (the default "
+                         "on the sphere clouds, c4 / c5s, where the tolerance build is NOT within that bar: rays graze "
+                         "hundreds of spheres and one flipped hit is another picture of the pixel): every operation "
                          "rounded like the reference's x86 build (pixels bit-identical to the reference's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-generic", action="store_true", help="skip the short extra run with the generic kernels")
@@ -225,6 +240,8 @@ def main():
     if world > 1 and args.scaling == "weak":
         W, H = grown_frame(W, H, world)
     builtin = scene_args is None
+    if args.numerics is None:
+        args.numerics = "fast" if builtin else "exact"
     scene = rt.Scene.builtin() if builtin else rt.Scene.synthetic(*scene_args)
     cam = rt.prepare_camera(scene, W, H, sqrt_spp, depth)
     plan = RowPlan(H, world)
@@ -303,9 +320,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    acc = {"k0_ms": 0.0, "k0_n": 0, "rays": 0, "shadow": 0, "culled": 0}
+    acc = {"k0_ms": 0.0, "k0_n": 0, "rays": 0, "shadow": 0, "culled": 0, "mib": 0}
+    done_at = []  # when each frame of the timed region was collected
 
     def tally(st):
+        done_at.append(time.perf_counter())
+        acc["mib"] = max(acc["mib"], st.work_mib)
         acc["k0_ms"] += st.k0_ms
         acc["k0_n"] += st.k0_launches
         acc["rays"] += st.primary_rays + st.shadow_rays + st.reflection_rays + st.transmission_rays
@@ -362,6 +382,9 @@ def main():
             "steps": steps,
             "warmup": warmup,
             "ms_per_step": dt_max / steps * 1e3,
+            # spread of the timed region: intervals between consecutive frames' completions on rank 0
+            "step_ms": (lambda d: {"p50": float(np.percentile(d, 50)), "p95": float(np.percentile(d, 95)),
+                                   "max": float(d.max())} if len(d) else None)(np.diff(np.array(done_at)) * 1e3),
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
@@ -380,6 +403,8 @@ def main():
                        "mrays_traced_per_s": (rays_all - culled_all) / dt_max / 1e6,
                        "numerics": args.numerics,
                        "frames_in_flight": inflight,
+                       "device_mib_per_context": acc["mib"],
+                       "device_mib": acc["mib"] * inflight + (W * my_rows * 4 * max(2, inflight) >> 20),
                        "streams": "one per frame" if args.overlap else ("shared + tail stream" if tail is not None else "shared"),
                        "render_stream_priority": args.render_priority,
                        "k_primary_launch_plan": args.launch_plan,
@@ -394,16 +419,30 @@ def main():
                          "traffic": None, "algorithmic_flop_per_launch": flops_k0 / launches_per_step,
                          "avg_launch_ms": k0_avg_ms},
         }
+        if not grid_scene and k0_avg_ms > 0:
+            # the same rate without the primary rays the kernel never generated (tiles shown to see nothing):
+            # each priced as the reference's miss - ray generation, every sphere rejected, every polygon behind
+            n_sph = 2 if builtin else scene_args[1]
+            n_pol = 1 if builtin else scene_args[2]
+            culled_flops = culled_all / max(steps, 1) / max(world, 1) * (50 + 20 * n_sph + 13 * n_pol)
+            tr = (flops_k0 - culled_flops) / launches_per_step / (k0_avg_ms * 1e-3) / 1e12
+            out["roofline"]["frac_traced"] = tr / PEAK_FP32_TFLOPS
+        if grid_scene:
+            out["roofline"]["kernel"] = "k_hits + k_trace(level 0): the primary rays and the rays of their hits"
         pmc = pmc_for(cfg, args.numerics) if world == 1 and (W, H, sqrt_spp, depth) == CONFIGS[cfg][1:5] else None
         if pmc:
             r = out["roofline"]
             r["traffic"] = pmc.get("hbm_bytes_per_launch")
-            r["traffic_unit"] = "bytes per launch (PMC, profiles/r02_pmc.json)"
+            r["traffic_unit"] = "bytes per launch (PMC, profiles/r03_pmc.json, kernels_sha %s)" % kernels_sha()
             lane_ops = pmc.get("valu_lane_ops_per_launch")
             if lane_ops and k0_avg_ms > 0:
                 # what the SIMDs can issue: one vector instruction (64 lanes) per 2 cycles per SIMD = peak / 2 lane-ops/s
                 r["executed_valu_lane_ops_per_launch"] = lane_ops
                 r["executed_frac"] = lane_ops / (k0_avg_ms * 1e-3) / (PEAK_FP32_TFLOPS * 1e12 / 2)
+            fp = pmc.get("fp_lane_flops_per_launch")
+            if fp and k0_avg_ms > 0:
+                # floating-point work really executed: 2 x FMA + MUL + ADD + transcendental instructions x active lanes
+                r["fp_executed_frac"] = fp / (k0_avg_ms * 1e-3) / (PEAK_FP32_TFLOPS * 1e12)
             for key in ("valu_busy", "lds_conflict_rate", "waves_per_simd"):
                 if key in pmc:
                     r[key] = pmc[key]

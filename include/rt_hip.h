@@ -157,7 +157,7 @@ typedef struct {
     /* k_primary launches of this render that followed a launch plan, and plans built at its end
      * (rt_hip_ctx_set_launch_plan) */
     uint32_t planned_launches, plan_builds;
-    uint32_t reserved2_;
+    uint32_t work_mib;          /* MiB of device memory the context holds for queues, nodes and per-sample arrays */
     uint32_t reserved_;
 } rt_hip_stats;
 
@@ -205,13 +205,15 @@ typedef struct rt_hip_ctx rt_hip_ctx;
 #define RT_E_OVERFLOW  (-10002)   /* ray/node queue overflow even at 1-row batches  */
 #define RT_E_NOSCENE   (-10003)   /* render before rt_hip_scene_upload              */
 
-/* Create a render context on HIP device `device` (-1 = current).  max_queue_rays = capacity
- * of each per-level ray queue and of the node pool, 152 bytes per entry.  0 = sized by the renders: the
- * first render allocates one entry per primary sample of its job (at least 1 Mi, at most
- * RT_HIP_QUEUE_CAP from the environment, else 256 Mi entries = 38 GiB of the GPU's 288: a 3840x2160 frame of
- * 4x4 samples is ONE batch of 19 GiB, which k_primary's launch plan needs and which pays the latency of the
- * tree's sparse deep levels once - 0.987 -> 0.853 ms for BASELINE config 3), a later, larger job re-allocates;
- * jobs beyond the capacity are rendered in row batches. */
+/* Create a render context on HIP device `device` (-1 = current).  max_queue_rays = capacity of each per-level
+ * hit queue and of the node pool, 152 bytes per entry.  0 = sized by the renders, from what they USE: the first
+ * frame of a shape gets an eighth of an entry per primary sample (at least 1 Mi entries) and is rendered in row
+ * batches; from the second frame on the context holds what the last frame of that shape needed per sample plus a
+ * quarter - 0.08 entries per sample for the reference's scene (a 1920x1080 x 16 spp context: 0.5 GiB; 3840x2160:
+ * 2 GiB), up to 2 for sphere clouds - so that the frame is ONE batch (k_primary's launch plan needs that, and
+ * every batch pays the latency of the tree's sparse deep levels once).  At most RT_HIP_QUEUE_CAP entries from
+ * the environment, else 256 Mi = 38 GiB of the GPU's 288; when the device cannot give that much the context
+ * settles for half, a quarter, ... and renders in batches.  stats.work_mib reports what is held. */
 int  rt_hip_ctx_create(rt_hip_ctx **out, int device, uint64_t max_queue_rays);
 void rt_hip_ctx_destroy(rt_hip_ctx *ctx);
 
@@ -366,7 +368,8 @@ void rt_launch_plan_order(const uint32_t *wave_ticks, uint32_t block_columns, ui
 
 /* Bracket the fused primary kernel with HIP events on the render stream (k0_ms). */
 void rt_hip_ctx_set_timing(rt_hip_ctx *ctx, int enable);
-/* Cap on primary samples per image batch (0 = automatic). */
+/* Primary samples per image batch, as given (0 = automatic: what the queues hold).  A batch that outgrows the
+ * queues is abandoned, halved and rendered again by rt_hip_finish. */
 void rt_hip_ctx_set_batch_samples(rt_hip_ctx *ctx, uint64_t max_samples);
 
 const char *rt_hip_last_error(void);

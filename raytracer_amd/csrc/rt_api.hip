@@ -122,7 +122,8 @@ struct rt_hip_ctx {
     uint32_t seen_hits[RT_MAX_LEVELS] = {0};
     uint32_t seen_nodes[RT_MAX_LEVELS] = {0};
     bool seen_valid = false;
-    double seen_density = 0.0; /* entries per sample the fullest shard of the last frame needed */
+    double seen_density = 0.0; /* entries per sample the fullest shard of the last frame's densest BATCH needed */
+    double seen_need = 0.0, seen_samples = 0.0; /* ... and of the whole frame: entries its batches needed, their samples */
     uint64_t seen_key[3] = {0, 0, 0}; /* frame the counts belong to: they are dropped when it changes */
     /*
      * Launch plan of k_primary.  The kernel is as long as the waves that start last and run longest, and the
@@ -474,6 +475,7 @@ void note_levels(rt_hip_ctx *c, const uint32_t *cnt, uint32_t levels, bool first
         memset(c->seen_hits, 0, sizeof c->seen_hits);
         memset(c->seen_nodes, 0, sizeof c->seen_nodes);
         c->seen_density = 0.0;
+        c->seen_need = c->seen_samples = 0.0;
     }
     /* entries the fullest shard needed per sample of this batch: its node range holds the nodes
      * of all levels, a queue the hits of one level (the next frame's batches are planned with it) */
@@ -495,6 +497,8 @@ void note_levels(rt_hip_ctx *c, const uint32_t *cnt, uint32_t levels, bool first
         const double density = (double)need * RT_SHARDS / (double)samples;
         if (density > c->seen_density)
             c->seen_density = density;
+        c->seen_need += (double)need * RT_SHARDS; /* (a frame in one batch needs at most the sum of its batches' needs) */
+        c->seen_samples += (double)samples;
     }
     for (uint32_t l = 0; l < levels && l + 1 < RT_MAX_LEVELS; ++l)
         for (uint32_t sh = 0; sh < RT_SHARDS; ++sh) {
@@ -666,6 +670,11 @@ void finish_stats(rt_hip_ctx *c)
     s.primary_rays = (uint64_t)c->C.W * rows * c->C.sqrtSpp * c->C.sqrtSpp;
     s.shadow_rays = s.shade_nodes * c->S.nLights;
     s.k0_shadow_rays = s.k0_shade_nodes * c->S.nLights;
+    /* device memory the context holds for its work: queues and nodes, per-pixel / per-sample arrays, loop queues */
+    const uint64_t bytes = (c->work_blob ? c->W.stride * 9u + c->W.stride / 2u : 0u) + c->pix_cap * sizeof(float4) + c->tile_cap +
+                           c->roots_cap * sizeof(uint32_t) + c->z_samples * (sizeof(uint2) + 2u * sizeof(float4)) + c->z_vis +
+                           (uint64_t)RT_SHARDS * c->W.loop_capS * 4u * sizeof(float4);
+    s.work_mib = (uint32_t)((bytes + (1u << 20) - 1u) >> 20);
 }
 
 int check_args(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb, uint32_t row0, uint32_t nrows)
@@ -703,13 +712,18 @@ uint64_t default_batch_samples(const rt_hip_ctx *c)
      * in which more than half the samples queue two hits are rare, and a batch that does outgrow
      * the queues is split and rendered again (drain), so the plan is one sample per entry. */
     uint64_t m = c->cap;
-    /* ... unless the last frame of the same shape showed that this scene needs more than one entry
-     * per sample (mirror-heavy scenes: config 4 queues 1.2 hits per sample): plan for that, with 15 %
-     * to spare, instead of rendering an oversized batch in vain first */
-    if (c->seen_valid && c->seen_density * 1.15 > 1.0)
-        m = (uint64_t)((double)c->cap / (c->seen_density * 1.15));
-    if (c->batch_samples && c->batch_samples < m)
-        m = c->batch_samples;
+    /* ... unless the last frame of the same shape showed what this scene needs per sample (the reference's
+     * scene 0.08 entries, mirror-heavy sphere clouds up to 2): plan for that, with 15 % to spare, instead of
+     * rendering an oversized batch in vain first - or many small ones where one would do */
+    if (c->seen_valid && c->seen_density > 0.0) {
+        /* the whole frame if it fits as one batch (its own entries per sample), else batches sized for the densest */
+        const double frame = c->seen_samples > 0.0 ? c->seen_need / c->seen_samples : c->seen_density;
+        const double all = (double)c->job.ntiles * 8.0 * c->C.W * c->C.sqrtSpp * c->C.sqrtSpp;
+        const double per = all * frame * 1.15 <= (double)c->cap ? all + 1.0 : (double)c->cap / (c->seen_density * 1.15);
+        m = per > 1.8e19 ? ~0ull : (uint64_t)per;
+    }
+    if (c->batch_samples)
+        m = c->batch_samples; /* the caller's plan, also when it is more than the queues hold (overflow: halved and rendered again) */
     return m ? m : 1;
 }
 
@@ -723,35 +737,53 @@ uint64_t round_cap(uint64_t cap)
 }
 
 /* (re)allocate the queues and the node pool for `cap` entries: one blob of 6 queue arrays + 3 node arrays of
- * cap float4 each + one of cap float2.  Nothing of this context may be in flight. */
+ * cap float4 each + one of cap float2.  Nothing of this context may be in flight.  The old blob is kept until the
+ * new one exists when the device has room for both; when even the new one alone does not fit (a shared GPU, a
+ * caching allocator holding the memory), a context that sizes itself settles for half, a quarter, ... down to
+ * 1 Mi entries - its frames are then rendered in row batches - and remembers the limit. */
 int ensure_work(rt_hip_ctx *c, uint64_t cap)
 {
     if (c->work_blob && c->cap == cap)
         return 0;
-    if (c->work_blob) {
-        HIP_TRY(hipFree(c->work_blob)); /* (waits for the device) */
-        c->work_blob = nullptr;
-        c->cap = 0;
+    for (;;) {
+        const size_t arr = align_up(cap * sizeof(float4), 256), bytes = arr * 9 + arr / 2;
+        void *blob = nullptr;
+        hipError_t e = hipMalloc(&blob, bytes);
+        if (e == hipErrorOutOfMemory && c->work_blob) { /* not beside the old one: without it, then */
+            (void)hipGetLastError();
+            HIP_TRY(hipFree(c->work_blob)); /* (waits for the device) */
+            c->work_blob = nullptr;
+            c->cap = 0;
+            e = hipMalloc(&blob, bytes);
+        }
+        if (e == hipSuccess) {
+            if (c->work_blob)
+                HIP_TRY(hipFree(c->work_blob));
+            c->work_blob = blob;
+            c->cap = cap;
+            c->W.base = (char *)blob; /* slots 0..9, the last one (float2) half as long: rt_device.h */
+            c->W.stride = arr;
+            c->W.cap = (uint32_t)cap;
+            c->W.capS = (uint32_t)(cap / RT_SHARDS);
+            break;
+        }
+        (void)hipGetLastError();
+        if (e != hipErrorOutOfMemory || !c->auto_cap || cap <= (1ull << 20)) {
+            c->work_blob = nullptr;
+            c->cap = 0;
+            set_err("allocating %zu bytes of queue memory (%llu entries) on device %d failed: %s", bytes,
+                    (unsigned long long)cap, c->device, hipGetErrorString(e));
+            return -(int)e;
+        }
+        cap = round_cap(cap / 2 < (1ull << 20) ? (1ull << 20) : cap / 2);
+        c->cap_limit = cap; /* larger jobs go in batches from now on */
     }
-    const size_t arr = align_up(cap * sizeof(float4), 256);
-    const hipError_t e = hipMalloc(&c->work_blob, arr * 9 + arr / 2);
-    if (e != hipSuccess) {
-        c->work_blob = nullptr;
-        set_err("allocating %zu bytes of queue memory (%llu entries) on device %d failed: %s", arr * 9 + arr / 2,
-                (unsigned long long)cap, c->device, hipGetErrorString(e));
-        return -(int)e;
-    }
-    c->cap = cap;
-    c->W.base = (char *)c->work_blob; /* slots 0..9, the last one (float2) half as long: rt_device.h */
-    c->W.stride = arr;
-    c->W.cap = (uint32_t)cap;
-    c->W.capS = (uint32_t)(cap / RT_SHARDS);
-    /* the job pipeline's loop queues (big scenes only): an eighth of the log's entries, 64 bytes each */
+    /* the job pipeline's loop queues (big scenes only) follow the capacity: ensure_loopq */
     if (c->loopq) {
         HIP_TRY(hipFree(c->loopq));
         c->loopq = nullptr;
     }
-    c->W.loopq = nullptr; /* (ensure_loopq, when a big scene is rendered) */
+    c->W.loopq = nullptr;
     c->W.loop_capS = 0;
     c->seen_valid = false;
     return 0;
@@ -1659,17 +1691,33 @@ static int submit(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb, float *
     drop_events(c);
     memset(&c->stats, 0, sizeof c->stats);
     if (c->auto_cap) {
-        /* one entry per primary sample of the job (the batch plan's rule), within [1 Mi, the limit]; the
-         * blob only ever grows */
-        uint64_t want = (uint64_t)job.ntiles * 8u * c->C.W * c->C.sqrtSpp * c->C.sqrtSpp;
-        /* ... times what the last frame of this shape needed per sample, if that was more (mirror-heavy
-         * scenes): every batch pays the latency of its sparse deep levels once, config 5's scene ~14 ms of
-         * a 75 ms frame when it was cut in two */
-        if (c->seen_valid && c->seen_density * 1.15 > 1.0)
-            want = (uint64_t)((double)want * c->seen_density * 1.15) + 1u;
+        /* A context that sizes itself holds what its frames USE, not what they could: a frame of the reference's
+         * scene needs 0.08 entries per primary sample, a sphere cloud up to 2.  The first frame of a shape gets an
+         * eighth of an entry per sample and is rendered in batches (a batch whose queues do overflow is halved and
+         * rendered again: drain); from the second frame on the capacity is what the last frame of the shape needed
+         * per sample, a quarter on top, so that the frame is ONE batch - which k_primary's launch plan needs, and
+         * which pays the latency of the tree's sparse deep levels once.  Within [1 Mi, the limit]; the blob only
+         * ever grows. */
+        const uint64_t samples = (uint64_t)job.ntiles * 8u * c->C.W * c->C.sqrtSpp * c->C.sqrtSpp;
+        const bool known = c->seen_valid && c->seen_samples > 0.0 && c->seen_need > 0.0;
+        uint64_t want = known ? (uint64_t)((double)samples * (c->seen_need / c->seen_samples) * 1.25) + 1u : samples / 8u;
         want = round_cap(want < (1ull << 20) ? (1ull << 20) : want > c->cap_limit ? c->cap_limit : want);
-        if (want > c->cap && (rc = ensure_work(c, want)))
-            return rc;
+        if (want > c->cap) {
+            const double density = c->seen_density, need = c->seen_need, of = c->seen_samples;
+            const bool valid = c->seen_valid;
+            uint32_t hits[RT_MAX_LEVELS], nodes[RT_MAX_LEVELS];
+            memcpy(hits, c->seen_hits, sizeof hits);
+            memcpy(nodes, c->seen_nodes, sizeof nodes);
+            if ((rc = ensure_work(c, want)))
+                return rc;
+            /* (what the last frame of this shape needed is still true with more room) */
+            c->seen_valid = valid;
+            c->seen_density = density;
+            c->seen_need = need;
+            c->seen_samples = of;
+            memcpy(c->seen_hits, hits, sizeof hits);
+            memcpy(c->seen_nodes, nodes, sizeof nodes);
+        }
     }
     c->pending = true;
     if (job.ntiles == 0)

@@ -906,6 +906,13 @@ __device__ __forceinline__ void stage_eye_terms(const DevScene &S, const DevCame
     }
 }
 
+/* The shard a tile's wave feeds.  A multiplicative hash of the tile's index: with the index modulo the shards, a
+ * compact object - the glass sphere of the reference's scene, a few dozen tiles wide and high - filled a few shards
+ * 3.4 times fuller than the average (a row of a 1920-pixel frame is 240 tiles, 48 modulo 64: a column of tiles
+ * meets only four shards), and the fullest shard is what a context's queues are sized for. */
+__device__ __forceinline__ uint32_t tile_shard(uint32_t tile) { return (tile * 2654435761u) >> 26; }
+static_assert(RT_SHARDS == 64, "tile_shard keeps the top six bits");
+
 /* counter line of (level, shard): low word = nodes made at `level`, high word = rays queued
  * for level+1 (rt_device.h) */
 __device__ __forceinline__ unsigned long long *level_line(uint32_t *counters, uint32_t level,
@@ -1848,8 +1855,8 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
     const float fv0 = ((C.hfbH - (float)y) / C.hfbH) * C.halfH;
 
     /* every wave feeds its own shard: even a single tile row spreads over all of them */
-    const uint32_t shard = ((ty * nbx + bx) * (RT_BLOCK / 64u) +
-                            (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) % RT_SHARDS;
+    const uint32_t shard = tile_shard((ty * nbx + bx) * (RT_BLOCK / 64u) +
+                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
     const uint32_t node_base = shard * Wk.capS; /* level 0 opens every shard's node range */
 
     float accr = 0.0f, accg = 0.0f, accb = 0.0f; /* color_init raytrace.c:908 */

@@ -24,6 +24,7 @@
 #include "rt_internal.h"
 
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <mutex>
 
 constexpr uint32_t kToneBlocks = 1024; /* partial sums per launch */
@@ -162,7 +163,8 @@ struct ToneScratch {
 std::mutex g_tone_mu;
 ToneScratch g_tone[64];
 
-double *g_static_ptr[64] = {nullptr}; /* device address of `scratch` per device (rt_tone_static_init) */
+std::atomic<double *> g_static_ptr[64]; /* device address of `scratch` per device (rt_tone_static_init writes it under g_tone_mu;
+                                           rt_hip_tone_static reads it without the lock) */
 
 int current_device(int *dev)
 {
@@ -232,7 +234,7 @@ int check_tone_args(const float *d_radiance, uint64_t npixels, int op, int64_t k
         rt_set_err("tone step: null frame or operator %d (RT_TONE_WARD, RT_TONE_REINHARD)", op);
         return RT_E_INVALID;
     }
-    if (key_pixel >= (int64_t)npixels) {
+    if (op == RT_TONE_REINHARD && key_pixel >= (int64_t)npixels) { /* (Ward's operator has no key pixel: whatever the caller left there is ignored) */
         rt_set_err("tone step: key pixel %lld outside the %llu pixels", (long long)key_pixel, (unsigned long long)npixels);
         return RT_E_INVALID;
     }
@@ -248,14 +250,14 @@ int rt_tone_static_init(void)
     if (rc)
         return rc;
     std::lock_guard<std::mutex> lk(g_tone_mu);
-    if (!g_static_ptr[dev]) {
+    if (!g_static_ptr[dev].load()) {
         double *ptr = nullptr;
         const hipError_t e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
         if (e != hipSuccess || !ptr) {
             rt_set_err("hipGetSymbolAddress(tone scratch) on device %d failed: %s", dev, hipGetErrorString(e));
             return e != hipSuccess ? -(int)e : RT_E_INVALID;
         }
-        g_static_ptr[dev] = ptr;
+        g_static_ptr[dev].store(ptr);
     }
     return 0;
 }
@@ -278,7 +280,7 @@ int rt_hip_tone_sums(const float *d_radiance, uint64_t npixels, float lMax, int6
         }
         return 0;
     }
-    int rc = check_tone_args(d_radiance, npixels, RT_TONE_WARD, key_pixel);
+    int rc = check_tone_args(d_radiance, npixels, RT_TONE_REINHARD, key_pixel); /* (the sums carry the key pixel's luminance) */
     if (rc)
         return rc;
     double *partial, *own;
@@ -336,9 +338,9 @@ int rt_hip_tone_static(float *d_radiance, uint32_t *d_argb, uint64_t npixels, in
     int dev = 0;
     if ((rc = current_device(&dev)))
         return rc;
-    if (!g_static_ptr[dev] && (rc = rt_tone_static_init())) /* first call on this device (no context made yet) */
+    if (!g_static_ptr[dev].load() && (rc = rt_tone_static_init())) /* first call on this device (no context made yet) */
         return rc;
-    double *const block = g_static_ptr[dev];
+    double *const block = g_static_ptr[dev].load();
     /* the kernels write every partial and every sum they later read: nothing of the last call's
      * contents needs clearing */
     return tone_with(block, block + 2 * kToneBlocks, d_radiance, d_argb, npixels, op, ldMax, lMax, key_pixel,

@@ -34,7 +34,11 @@ def test_single_gpu_line_has_the_contract_fields(tail):
     assert 0 < d["config"]["rays_traced_per_step"] < d["config"]["rays_per_step"]   # sky tiles are never generated
     assert d["generic_kernels"]["k_primary_ms"] > d["roofline"]["avg_launch_ms"] * 0.9
     alone = d["roofline"]["one_frame_at_a_time"]   # the kernel without a neighbour: not slower than beside one
-    assert 0 < alone["k_primary_ms"] <= d["roofline"]["avg_launch_ms"] * 1.1 and 0.05 < alone["frac"] < 1.0
+    # (six timed frames on a GPU whose clocks may still be settling: a loose bound)
+    assert 0 < alone["k_primary_ms"] <= d["roofline"]["avg_launch_ms"] * 1.35 and 0.05 < alone["frac"] < 1.0
+    assert d["step_ms"]["p50"] <= d["step_ms"]["p95"] <= d["step_ms"]["max"]
+    assert 0 < d["config"]["device_mib_per_context"] <= 1024      # sized from what the frame uses (0.08 entries a sample)
+    assert 0 < d["roofline"]["frac_traced"] < d["roofline"]["frac"]
     assert alone["ms_per_step_one_frame_at_a_time"] > d["ms_per_step"] * 0.9
     assert d["vs_baseline"] is None and d["higher_is_better"] is True
     assert "workload" in d["config"] and "1920x1080" in d["config"]["workload"]
@@ -72,6 +76,7 @@ def test_other_workloads_and_weak_scaling_are_selectable():
     d = run_bench(["--config", "c4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
     assert "1024 spheres" in d["config"]["workload"] and "3840x2160" in d["config"]["workload"]
     assert d["value"] > 1e3 and "generic_kernels" not in d
+    assert d["config"]["numerics"] == "exact"   # the sphere clouds default to the build that is pinned there
     d = run_bench(["--gpus", "2", "--config", "c2", "--scaling", "weak", "--steps", "4", "--warmup", "1"],
                   {"RT_BENCH_REHEARSE_WORLD": "2", "RT_BENCH_REHEARSE_RANK": "0"})
     assert d["scaling"] == "weak" and "1920x1080" not in d["config"]["workload"]

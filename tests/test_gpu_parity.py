@@ -997,6 +997,7 @@ def test_tail_stream_with_small_queues_and_overflow_retries(torch_cuda, make_sce
     small = rt.Context(queue_cap=1 << 19)
     small.upload(sc)
     small.set_tail_stream(tail.cuda_stream)
+    small.set_batch_samples(1 << 19)  # (a context that knows the frame would plan it as one batch: it needs 0.1 entries a sample)
     retries = 0
     for _ in range(3):
         argb = torch.zeros_like(want)
