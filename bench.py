@@ -207,6 +207,7 @@ def main():
                          "hundreds of spheres and one flipped hit is another picture of the pixel): every operation "
                          "rounded like the reference's x86 build (pixels bit-identical to the reference's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-one-shot", action="store_true", help="skip the child processes that time the blocking raytrace() call")
     ap.add_argument("--no-generic", action="store_true", help="skip the short extra run with the generic kernels")
     args = ap.parse_args()
 
@@ -483,6 +484,15 @@ def main():
                     one_at_a_time(g), note="30 frames, one at a time, with the kernels every scene shape other than the "
                                            "reference's gets (rt_hip_ctx_set_specialization(ctx, 0))")
                 g.set_specialization(True)
+        if world == 1 and builtin and not args.no_one_shot:
+            # the call the reference's main() makes - raytrace() with the pixels in the caller's pageable buffer - timed in
+            # child processes: a cold process from exec to exit, and the same process calling it frame after frame
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import one_shot
+            try:
+                out["one_shot"] = one_shot.measure(W, H, sqrt_spp, depth)
+            except Exception as e:  # noqa: BLE001 - the bench line must still print
+                out["one_shot"] = {"error": str(e)[-300:]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, builtin, W, H, sqrt_spp, depth)
         print(json.dumps(out), flush=True)

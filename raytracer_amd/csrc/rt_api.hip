@@ -8,12 +8,16 @@
 #include "rt_internal.h"
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <thread>
 #include <cmath>
 #include <mutex>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <vector>
 
 namespace {
@@ -107,6 +111,13 @@ struct rt_hip_ctx {
     uint64_t cap_limit = 0; /* ... up to this many entries */
     /* optional second stream for the latency-bound tail of a batch (rt_hip_ctx_set_tail_stream) */
     hipStream_t tail_stream = nullptr;
+    /* "early copy" (the blocking host path, rt_hip_render): a pinned, device-mapped host frame that holds the packed
+     * pixels when the batch is done.  k_primary finishes most pixels of a frame (85 % at the reference's scene); one
+     * copy of the batch's rows leaves for the host behind it, beside the levels and folds, and k_resolve - which waits
+     * for that copy - stores the pixels it finishes both to the device frame and straight into the host's. */
+    uint32_t *early_host = nullptr, *early_alias = nullptr; /* host address, device address of the same memory */
+    hipStream_t early_stream = nullptr;
+    hipEvent_t early_from = nullptr, early_done = nullptr;
     hipEvent_t head_done = nullptr, tail_done = nullptr;
     bool tail_pending = false;  /* a tail of this context was enqueued and may still run         */
     bool round_on_tail = false; /* the round in flight ends on the tail stream                    */
@@ -374,6 +385,11 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
             (fast ? rt_launch_jobs_shadefold_fast : rt_launch_jobs_shadefold)(c->S, c->C, Wk, Z, d, expect, st);
         }
         (fast ? rt_launch_jobs_resolve_fast : rt_launch_jobs_resolve)(c->S, c->C, Wk, R, Z, st);
+        if (c->early_alias && c->d_argb && !c->job.interleaved) { /* every pixel is finished by the resolve: the rows follow it */
+            const size_t off = (size_t)R.out_first * c->C.W;
+            const uint32_t rows = (!c->job.interleaved && R.y_first + R.ntiles * 8u > R.y_limit) ? R.y_limit - R.y_first : R.ntiles * 8u;
+            HIP_TRY(hipMemcpyAsync(c->early_host + off, c->d_argb + off, (size_t)rows * c->C.W * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        }
         rt_launch_publish(Wk.counters, c->h_counters_dev + (size_t)b.slot * c->cwords, (uint32_t)c->cwords, st);
         HIP_TRY(hipGetLastError());
         return 0;
@@ -386,6 +402,16 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
         rt_launch_primary(c->S, c->C, Wk, R, stats, c->shading == RT_SHADE_PHONGBLINN, st);
     if (timed)
         HIP_TRY(hipEventRecord(c->ev.back(), st));
+    const bool early = c->early_alias && !stats && c->d_argb && !c->job.interleaved;
+    const size_t early_off = (size_t)R.out_first * c->C.W;
+    const uint32_t early_rows = (!c->job.interleaved && R.y_first + R.ntiles * 8u > R.y_limit) ? R.y_limit - R.y_first : R.ntiles * 8u;
+    if (early) {
+        HIP_TRY(hipEventRecord(c->early_from, st));
+        HIP_TRY(hipStreamWaitEvent(c->early_stream, c->early_from, 0));
+        HIP_TRY(hipMemcpyAsync(c->early_host + early_off, c->d_argb + early_off, (size_t)early_rows * c->C.W * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, c->early_stream));
+        HIP_TRY(hipEventRecord(c->early_done, c->early_stream));
+    }
     auto to_tail = [&]() -> int {
         HIP_TRY(hipEventRecord(c->head_done, st));
         st = c->tail_stream;
@@ -446,7 +472,12 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
     }
     for (uint32_t d = fold_from; d-- > 1;)
         rt_launch_fold(Wk, d, c->seen_valid ? (c->seen_nodes[d] ? c->seen_nodes[d] : 1u) : 0u, st);
-    rt_launch_resolve(c->C, Wk, R, c->d_argb, c->d_rad, st);
+    if (early)
+        HIP_TRY(hipStreamWaitEvent(st, c->early_done, 0));
+    rt_launch_resolve(c->C, Wk, R, c->d_argb, c->d_rad, early ? c->early_alias : nullptr, st);
+    if (c->early_alias && !early && c->d_argb && !c->job.interleaved) /* (instrumented renders: the rows follow the resolve) */
+        HIP_TRY(hipMemcpyAsync(c->early_host + early_off, c->d_argb + early_off, (size_t)early_rows * c->C.W * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, st));
     rt_launch_publish(Wk.counters, c->h_counters_dev + (size_t)b.slot * c->cwords, (uint32_t)c->cwords, st);
     if (cut) {
         HIP_TRY(hipEventRecord(c->tail_done, st));
@@ -950,6 +981,9 @@ void rt_hip_ctx_destroy(rt_hip_ctx *c)
     }
     drop_events(c);
     if (c->round_done) (void)hipEventDestroy(c->round_done);
+    if (c->early_from) (void)hipEventDestroy(c->early_from);
+    if (c->early_done) (void)hipEventDestroy(c->early_done);
+    if (c->early_stream) (void)hipStreamDestroy(c->early_stream);
     if (c->head_done) (void)hipEventDestroy(c->head_done);
     if (c->tail_done) (void)hipEventDestroy(c->tail_done);
     if (c->scene_blob) (void)hipFree(c->scene_blob);
@@ -1885,6 +1919,97 @@ int staged_copy_back(void *dst, const void *d_src, size_t bytes)
 }
 } // namespace
 
+/* The blocking host path's pixels: the kernels store the packed frame straight into pinned, device-mapped host
+ * memory (the stores go over the link while the kernels still run), and a few threads move it from there into the
+ * caller's pageable buffer - one memcpy of a 1080p frame is 0.3 ms, a third of a warm raytrace() call. */
+namespace {
+uint32_t *g_hargb = nullptr, *g_hargb_dev = nullptr; /* pinned + mapped frame, its device address */
+size_t g_hargb_px = 0;
+
+class CopyPool { /* persistent helpers: each copies a slice; they spin briefly between jobs (frames come back to back), then sleep */
+public:
+    static CopyPool &get()
+    {
+        static CopyPool p;
+        return p;
+    }
+    void copy(void *dst, const void *src, size_t bytes)
+    {
+        const int n = (int)workers_.size() + 1;
+        if (n == 1 || bytes < ((size_t)1 << 20)) {
+            memcpy(dst, src, bytes);
+            return;
+        }
+        const size_t slice = ((bytes / n) + 4095) & ~(size_t)4095;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            dst_ = (char *)dst; src_ = (const char *)src; bytes_ = bytes; slice_ = slice;
+            pending_ = n - 1;
+            ++generation_;
+        }
+        cv_.notify_all();
+        memcpy(dst, src, slice < bytes ? slice : bytes); /* slice 0: this thread */
+        while (pending_.load(std::memory_order_acquire) != 0)
+            std::this_thread::yield();
+    }
+    ~CopyPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+            ++generation_;
+        }
+        cv_.notify_all();
+        for (std::thread &t : workers_)
+            t.join();
+    }
+
+private:
+    CopyPool()
+    {
+        const char *e = getenv("RT_HIP_COPY_THREADS");
+        int n = e && *e ? atoi(e) : 4;
+        n = n < 1 ? 1 : (n > 16 ? 16 : n);
+        for (int i = 1; i < n; ++i)
+            workers_.emplace_back([this, i] { run(i); });
+    }
+    void run(int index)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            /* spin for the next job for a while, then wait on the condition variable */
+            bool got = false;
+            for (int spin = 0; spin < 20000 && !got; ++spin) {
+                if (generation_.load(std::memory_order_acquire) != seen)
+                    got = true;
+                else
+                    __builtin_ia32_pause();
+            }
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return generation_.load() != seen; });
+                seen = generation_.load();
+                if (stop_)
+                    return;
+            }
+            const size_t off = slice_ * (size_t)index;
+            if (off < bytes_)
+                memcpy(dst_ + off, src_ + off, bytes_ - off < slice_ ? bytes_ - off : slice_);
+            pending_.fetch_sub(1, std::memory_order_release);
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::atomic<uint64_t> generation_{0};
+    std::atomic<int> pending_{0};
+    bool stop_ = false;
+    char *dst_ = nullptr;
+    const char *src_ = nullptr;
+    size_t bytes_ = 0, slice_ = 0;
+};
+} // namespace
+
 /* RT_HIP_SHADING=phongblinn: the host-pointer entry points shade with the reference's older routine (the
  * reference itself switches by editing the call at raytrace.c:706) */
 static int shading_from_env(void)
@@ -1921,6 +2046,16 @@ int rt_hip_render(const rt_scene *scene, const rt_camera *cam, rt_framebuffer *f
     }
     std::lock_guard<std::mutex> lk(g_mu);
     int rc;
+    /* RT_HIP_TIMES=1: where the call's time goes, to stderr (development; tools/one_shot.py) */
+    static const bool times = getenv("RT_HIP_TIMES") != nullptr;
+    struct timespec ts0;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
+    auto since = [&]() {
+        struct timespec t;
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        return (double)(t.tv_sec - ts0.tv_sec) * 1e3 + (double)(t.tv_nsec - ts0.tv_nsec) * 1e-6;
+    };
+    double t_ctx = 0.0, t_upload = 0.0, t_buffers = 0.0, t_render = 0.0;
     /* "the current HIP device": the cached context and frame buffers follow the caller when it has
      * switched devices since the last call */
     int current = 0;
@@ -1931,8 +2066,9 @@ int rt_hip_render(const rt_scene *scene, const rt_camera *cam, rt_framebuffer *f
         g_ctx = nullptr;
         if (g_argb) (void)hipFree(g_argb);
         if (g_rad) (void)hipFree(g_rad);
-        g_argb = nullptr; g_rad = nullptr;
-        g_argb_px = g_rad_px = 0;
+        if (g_hargb) (void)hipHostFree(g_hargb);
+        g_argb = nullptr; g_rad = nullptr; g_hargb = g_hargb_dev = nullptr;
+        g_argb_px = g_rad_px = g_hargb_px = 0;
         HIP_TRY(hipSetDevice(current));
     }
     /* queue capacity sized to the job: 2 entries per primary sample, 1 Mi .. default */
@@ -1949,6 +2085,7 @@ int rt_hip_render(const rt_scene *scene, const rt_camera *cam, rt_framebuffer *f
         if (rc)
             return rc;
     }
+    t_ctx = since();
     rc = rt_hip_ctx_set_shading(g_ctx, shading_from_env());
     if (!rc)
         rc = rt_hip_ctx_set_numerics(g_ctx, numerics_from_env());
@@ -1957,6 +2094,7 @@ int rt_hip_render(const rt_scene *scene, const rt_camera *cam, rt_framebuffer *f
     rc = rt_hip_scene_upload(g_ctx, scene);
     if (rc)
         return rc;
+    t_upload = since();
     const size_t npix = (size_t)fb->width * fb->height;
     if (npix > g_argb_px) {
         if (g_argb)
@@ -1976,15 +2114,42 @@ int rt_hip_render(const rt_scene *scene, const rt_camera *cam, rt_framebuffer *f
     }
     uint32_t *d_argb = g_argb;
     float *d_rad = fb->radiance ? g_rad : nullptr;
+    /* the packed pixels reach the host in pinned, mapped memory, most of them while the frame is still being
+     * finished (rt_hip_ctx::early_host); RT_HIP_NO_EARLY_COPY=1: one staged copy after the frame, as for the radiance */
+    static const bool mapped = getenv("RT_HIP_NO_EARLY_COPY") == nullptr;
+    if (mapped && npix > g_hargb_px) {
+        if (g_hargb)
+            (void)hipHostFree(g_hargb);
+        g_hargb = g_hargb_dev = nullptr;
+        g_hargb_px = 0;
+        HIP_TRY(hipHostMalloc((void **)&g_hargb, npix * sizeof(uint32_t), hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void **)&g_hargb_dev, g_hargb, 0));
+        g_hargb_px = npix;
+    }
+    if (mapped && !g_ctx->early_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&g_ctx->early_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&g_ctx->early_from, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&g_ctx->early_done, hipEventDisableTiming));
+    }
+    g_ctx->early_host = mapped ? g_hargb : nullptr;
+    g_ctx->early_alias = mapped ? g_hargb_dev : nullptr;
+    t_buffers = since();
     rc = rt_hip_render_rows(g_ctx, cam, d_argb, d_rad, fb->row0, fb->nrows, nullptr);
     if (!rc)
         rc = rt_hip_finish(g_ctx, nullptr);
+    t_render = since();
     if (!rc && fb->nrows) {
         const size_t off = (size_t)fb->row0 * fb->width, cnt = (size_t)fb->nrows * fb->width;
-        rc = staged_copy_back(fb->argb + off, d_argb + off, cnt * sizeof(uint32_t));
+        if (mapped)
+            CopyPool::get().copy(fb->argb + off, g_hargb + off, cnt * sizeof(uint32_t));
+        else
+            rc = staged_copy_back(fb->argb + off, d_argb + off, cnt * sizeof(uint32_t));
         if (!rc && fb->radiance)
             rc = staged_copy_back(fb->radiance + 3 * off, d_rad + 3 * off, cnt * 3 * sizeof(float));
     }
+    if (times)
+        fprintf(stderr, "rt_hip_render: context %.3f ms, scene %.3f, buffers %.3f, render %.3f, pixels back %.3f, total %.3f ms\n",
+                t_ctx, t_upload - t_ctx, t_buffers - t_upload, t_render - t_buffers, since() - t_render, since());
     return rc;
 }
 

@@ -283,7 +283,7 @@ void rt_launch_subtree_fast(const DevScene &S, const DevCamera &C, const DevWork
                             uint32_t expect, hipStream_t stream);
 void rt_launch_fold(const DevWork &Wk, uint32_t level, uint32_t expect, hipStream_t stream);
 void rt_launch_resolve(const DevCamera &C, const DevWork &Wk, const DevRows &R, uint32_t *d_argb,
-                       float *d_radiance, hipStream_t stream);
+                       float *d_radiance, uint32_t *d_argb_host, hipStream_t stream);
 size_t rt_scene_lds_bytes(const DevScene &S);
 /* the job pipeline of big scenes (rt_jobs.inc), exact build and tolerance build (`_fast`) */
 void rt_launch_jobs_hits(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,

@@ -1799,8 +1799,8 @@ template <> __device__ __forceinline__ void fix_shape<1>(DevScene &S)
 
 /* a pixel's sum of sample colours -> the frame: x 1/spp^2 (raytrace.c:779), radiance, 8-bit pack (raytrace.c:783-790).
  * p: pixel of the batch.  k_resolve's last step, and k_primary's for the tiles without roots. */
-__device__ __forceinline__ void store_pixel(const DevCamera &C, const DevRows &R, size_t p, float r, float g, float b,
-                                            uint32_t *argb, float *radiance)
+__device__ __forceinline__ uint32_t store_pixel(const DevCamera &C, const DevRows &R, size_t p, float r, float g, float b,
+                                                uint32_t *argb, float *radiance)
 {
     r = r * C.scale; g = g * C.scale; b = b * C.scale;
     const size_t o = (size_t)R.out_first * C.W + p;
@@ -1811,7 +1811,9 @@ __device__ __forceinline__ void store_pixel(const DevCamera &C, const DevRows &R
     const uint32_t R8 = (uint32_t)(int)(255.0f * r) & 0xFFu;
     const uint32_t G8 = (uint32_t)(int)(255.0f * g) & 0xFFu;
     const uint32_t B8 = (uint32_t)(int)(255.0f * b) & 0xFFu;
-    argb[o] = 0xFF000000u | (R8 << 16) | (G8 << 8) | B8;
+    const uint32_t packed = 0xFF000000u | (R8 << 16) | (G8 << 8) | B8;
+    argb[o] = packed;
+    return packed;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -2437,7 +2439,7 @@ __global__ __launch_bounds__(RT_BLOCK * RT_DEEP_SUB) void k_fold_deep(DevWork Wk
 #define RT_RESOLVE_GRID 4096u
 #endif
 __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DevCamera C, DevWork Wk, DevRows R,
-                                                      uint32_t *argb, float *radiance)
+                                                      uint32_t *argb, float *radiance, uint32_t *argb_host)
 {
     if (overflowed_before(Wk.counters))
         return; /* rows of an abandoned batch are rendered again by the host in smaller batches */
@@ -2488,7 +2490,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DevCamera C, DevWork Wk, D
                 }
             }
         }
-        store_pixel(C, R, p, r, g, b, argb, radiance);
+        const uint32_t packed = store_pixel(C, R, p, r, g, b, argb, radiance);
+        /* the blocking host path: k_primary's pixels went to the host in a copy beside the levels; these follow
+         * them straight into its mapped buffer (rt_api.hip, "early copy") */
+        if (argb_host)
+            argb_host[(size_t)R.out_first * C.W + p] = packed;
     }
 }
 
@@ -2782,14 +2788,14 @@ void rt_launch_fold(const DevWork &Wk, uint32_t level, uint32_t expect, hipStrea
 }
 
 void rt_launch_resolve(const DevCamera &C, const DevWork &Wk, const DevRows &R, uint32_t *d_argb,
-                       float *d_radiance, hipStream_t stream)
+                       float *d_radiance, uint32_t *d_argb_host, hipStream_t stream)
 {
     size_t grid = (size_t)((C.W + 31u) / 32u) * R.ntiles; /* blocks of 32x8 pixels, as k_primary's */
     if (grid > RT_RESOLVE_GRID)
         grid = RT_RESOLVE_GRID;
     if (grid == 0)
         grid = 1;
-    k_resolve<<<(uint32_t)grid, RT_BLOCK, 0, stream>>>(C, Wk, R, d_argb, d_radiance);
+    k_resolve<<<(uint32_t)grid, RT_BLOCK, 0, stream>>>(C, Wk, R, d_argb, d_radiance, d_argb_host);
 }
 
 void rt_launch_selftest_arith(const float *a, const float *b, const float *c, uint32_t n, float *out,

@@ -24,7 +24,12 @@ def run_bench(args, env_extra=None):
 
 @pytest.mark.parametrize("tail", ["on", "off"])
 def test_single_gpu_line_has_the_contract_fields(tail):
-    d = run_bench(["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--tail-stream", tail, "--numerics", "exact"])
+    d = run_bench(["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--tail-stream", tail, "--numerics", "exact"] +
+                  ([] if tail == "on" else ["--no-one-shot"]))
+    if tail == "on":   # the blocking raytrace() call in child processes: cold from exec to exit, warm per call
+        for num in ("exact", "fast"):
+            o = d["one_shot"][num]
+            assert 0.2 < o["warm_call_ms_min"] <= o["warm_call_ms_p50"] < 2.0 and 20.0 < o["cold_process_ms"] < 5000.0
     assert d["config"]["streams"] == ("shared + tail stream" if tail == "on" else "shared")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline"):
@@ -71,7 +76,7 @@ def test_rank_of_a_multi_gpu_run_on_the_shared_stream():
 
 
 def test_other_workloads_and_weak_scaling_are_selectable():
-    d = run_bench(["--config", "c1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"])
+    d = run_bench(["--config", "c1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-one-shot"])
     assert "640x480" in d["config"]["workload"] and d["n_gpus"] == 1 and 0 < d["roofline"]["frac"] < 1.0
     d = run_bench(["--config", "c4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
     assert "1024 spheres" in d["config"]["workload"] and "3840x2160" in d["config"]["workload"]
