@@ -263,7 +263,8 @@ def main():
     tail = torch.cuda.Stream(device=dev) if args.tail_stream == "on" and not args.overlap else None
     ctxs = []
     for _ in range(inflight):
-        c = rt.Context(device=local_rank)  # queue capacity sized by the first render of this rank's share
+        # queue capacity sized by the first render of this rank's share (development: RT_BENCH_QUEUE_CAP fixes it)
+        c = rt.Context(device=local_rank, queue_cap=int(os.environ.get("RT_BENCH_QUEUE_CAP", "0")))
         c.upload(scene)
         c.set_numerics(numerics)
         c.set_launch_plan(args.launch_plan == "on")

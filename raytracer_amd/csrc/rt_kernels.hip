@@ -910,7 +910,11 @@ __device__ __forceinline__ void stage_eye_terms(const DevScene &S, const DevCame
  * compact object - the glass sphere of the reference's scene, a few dozen tiles wide and high - filled a few shards
  * 3.4 times fuller than the average (a row of a 1920-pixel frame is 240 tiles, 48 modulo 64: a column of tiles
  * meets only four shards), and the fullest shard is what a context's queues are sized for. */
+#ifdef RT_DEV_SHARD_MODULO /* development: the old rule */
+__device__ __forceinline__ uint32_t tile_shard(uint32_t tile) { return tile % RT_SHARDS; }
+#else
 __device__ __forceinline__ uint32_t tile_shard(uint32_t tile) { return (tile * 2654435761u) >> 26; }
+#endif
 static_assert(RT_SHARDS == 64, "tile_shard keeps the top six bits");
 
 /* counter line of (level, shard): low word = nodes made at `level`, high word = rays queued

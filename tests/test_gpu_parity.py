@@ -897,6 +897,34 @@ def test_contexts_size_themselves_from_their_frames(torch_cuda, make_scene):
     ctx.close()
 
 
+def test_a_limit_on_the_queues_means_more_batches_not_other_pixels(torch_cuda, make_scene, monkeypatch):
+    """RT_HIP_QUEUE_CAP: the most entries a self-sizing context may grow its queues to (what a GPU with little free
+    memory does to it by itself: ensure_work halves the capacity it asks for until the allocation fits, and keeps
+    the limit).  The frame then takes several batches - and shows the same pixels, radiance and counters."""
+    torch = torch_cuda
+    sc = make_scene("c5")
+    W, H, s, d = 960, 540, 2, 16
+    cam = rt.prepare_camera(sc, W, H, s, d)
+    ref = rt.Context(queue_cap=1 << 24)
+    ref.upload(sc)
+    want, want_rad, st0 = render_dev(torch, ref, cam)
+    ref.close()
+    monkeypatch.setenv("RT_HIP_QUEUE_CAP", str(1 << 19))
+    ctx = rt.Context()
+    monkeypatch.delenv("RT_HIP_QUEUE_CAP")
+    ctx.upload(sc)
+    for i in range(3):
+        argb, rad, st = render_dev(torch, ctx, cam)
+        assert np.array_equal(argb, want) and np.array_equal(rad.view(np.uint32), want_rad.view(np.uint32))
+        assert (st.shade_nodes, st.reflection_rays, st.transmission_rays) == \
+            (st0.shade_nodes, st0.reflection_rays, st0.transmission_rays)
+        assert st.batches > 1, (i, st.batches)           # 2.07 M samples never fit 0.5 Mi entries
+        assert 0 < st.work_mib < st0.work_mib // 4, (st.work_mib, st0.work_mib)  # the limit held
+        if i:
+            assert st.overflow_retries == 0, (i, st.overflow_retries)  # the batches are planned for the limit
+    ctx.close()
+
+
 def test_tail_stream_changes_nothing(torch_cuda, make_scene):
     """rt_hip_ctx_set_tail_stream: the sparse levels, folds and resolve of every batch on a second stream.
     Same pixels, radiance bits and counters as on one stream - for a single batch, for a frame cut into

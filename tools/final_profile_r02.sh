@@ -15,7 +15,7 @@ for num in fast exact; do
               "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_LDS_CMD_FIFO_FULL" \
               "FETCH_SIZE" "WRITE_SIZE"; do
     n=$((n+1))
-    timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d gpurun_out/pmc_${tag}_${num}_$n -- python3 bench.py --steps 10 --warmup 1 --no-cpu-baseline --no-generic --tail-stream off --numerics $num > gpurun_out/pmc_${tag}_${num}_$n.log 2>&1 || { tail -5 gpurun_out/pmc_${tag}_${num}_$n.log; exit 1; }
+    timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d gpurun_out/pmc_${tag}_${num}_$n -- python3 bench.py --steps 10 --warmup 1 --no-cpu-baseline --no-one-shot --no-generic --tail-stream off --numerics $num > gpurun_out/pmc_${tag}_${num}_$n.log 2>&1 || { tail -5 gpurun_out/pmc_${tag}_${num}_$n.log; exit 1; }
   done
 done
 python3 tools/pmc_json.py $tag > gpurun_out/pmc_$tag.json && head -c 1500 gpurun_out/pmc_$tag.json

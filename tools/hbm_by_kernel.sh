@@ -2,7 +2,7 @@
 # development: HBM bytes per kernel launch (FETCH_SIZE / WRITE_SIZE, one rocprofv3 run each) of a short one-stream bench run
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for pass in FETCH_SIZE WRITE_SIZE; do
-  timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d gpurun_out/hbm_$pass -- python3 bench.py --steps 10 --warmup 1 --no-cpu-baseline --no-generic --tail-stream off > gpurun_out/hbm_$pass.log 2>&1 || { tail -5 gpurun_out/hbm_$pass.log; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d gpurun_out/hbm_$pass -- python3 bench.py --steps 10 --warmup 1 --no-cpu-baseline --no-one-shot --no-generic --tail-stream off > gpurun_out/hbm_$pass.log 2>&1 || { tail -5 gpurun_out/hbm_$pass.log; exit 1; }
 done
 python3 - <<'PY'
 import csv, glob, re, collections

@@ -2,7 +2,7 @@
 # usage: tools/pmc_bench.sh <tag> "<bench args>" <counters...>   (run on the GPU box from the repo root)
 tag=$1; shift; bargs=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_$tag -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline $bargs > gpurun_out/pmc_$tag.log 2>&1 || { tail -5 gpurun_out/pmc_$tag.log; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_$tag -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-one-shot $bargs > gpurun_out/pmc_$tag.log 2>&1 || { tail -5 gpurun_out/pmc_$tag.log; exit 1; }
 python3 - <<PY
 import csv,glob,collections,re
 f=glob.glob("gpurun_out/pmc_$tag/**/*counter_collection.csv",recursive=True)[0]
