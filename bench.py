@@ -74,6 +74,7 @@ CONFIGS = {
     "c3": (None, 3840, 2160, 4, 8, 60, 10),
     "c4": ((0xC0FFEE04, 1024, 4, 1, 0), 3840, 2160, 4, 8, 6, 2),
     "c5s": ((0xC0FFEE05, 16384, 0, 8, 1), 1920, 1080, 2, 16, 4, 1),
+    "c5": ((0xC0FFEE05, 16384, 0, 8, 1), 7680, 4320, 8, 16, 2, 1),   # BASELINE config 5 at full size: a job for 8 GPUs
 }
 
 
@@ -259,7 +260,10 @@ def main():
     # k_primary of the roofline is the kernel and not the kernel plus its neighbours (0.106 against 0.18-0.21 ms).
     if (world > 1 or cfg != "c2") and not args.shared_stream:
         args.overlap = True
-    inflight = max(1, args.inflight if args.inflight is not None else (6 if args.overlap else 3))
+    # (the sphere clouds: two frames in flight - a 4K frame of config 4 in one batch holds 42 GB of hits, six of them
+    # would fill the GPU, and two already hide each other's sparse levels: 44.3 ms a frame against 44.7 with six;
+    # RT_HIP_QUEUE_CAP=33554432 renders it in twelve batches out of 5.9 GB, at 48.1 ms)
+    inflight = max(1, args.inflight if args.inflight is not None else ((6 if builtin else 2) if args.overlap else 3))
     tail = torch.cuda.Stream(device=dev) if args.tail_stream == "on" and not args.overlap else None
     ctxs = []
     for _ in range(inflight):
@@ -311,7 +315,7 @@ def main():
     i = 0
     while i < 2 * inflight or (i < 64 and time.perf_counter() - t_setup < 0.03):
         pipe.submit(i)
-        pipe.collect(i)
+        pipe.collect(i, sizing=i < inflight)  # (a context's first frame: rendered in batches, some of them twice)
         i += 1
     for i in range(warmup):
         pipe.submit(i)
@@ -322,12 +326,14 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    acc = {"k0_ms": 0.0, "k0_n": 0, "rays": 0, "shadow": 0, "culled": 0, "mib": 0}
+    acc = {"k0_ms": 0.0, "k0_n": 0, "rays": 0, "shadow": 0, "culled": 0, "mib": 0, "batches": 0, "retries": 0}
     done_at = []  # when each frame of the timed region was collected
 
     def tally(st):
         done_at.append(time.perf_counter())
         acc["mib"] = max(acc["mib"], st.work_mib)
+        acc["batches"] += st.batches
+        acc["retries"] += st.overflow_retries
         acc["k0_ms"] += st.k0_ms
         acc["k0_n"] += st.k0_launches
         acc["rays"] += st.primary_rays + st.shadow_rays + st.reflection_rays + st.transmission_rays
@@ -405,6 +411,7 @@ def main():
                        "mrays_traced_per_s": (rays_all - culled_all) / dt_max / 1e6,
                        "numerics": args.numerics,
                        "frames_in_flight": inflight,
+                       "batches_per_frame": acc["batches"] / max(steps, 1), "overflow_retries": acc["retries"],
                        "device_mib_per_context": acc["mib"],
                        "device_mib": acc["mib"] * inflight + (W * my_rows * 4 * max(2, inflight) >> 20),
                        "streams": "one per frame" if args.overlap else ("shared + tail stream" if tail is not None else "shared"),

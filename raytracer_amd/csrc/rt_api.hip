@@ -637,9 +637,14 @@ int rebuild_plan(rt_hip_ctx *c)
 
 /* Wait for the round in flight; batches whose queues overflowed go back on the work list as two
  * halves, the others add their counters to the statistics.  Repeats until the list is empty. */
+int ensure_work(rt_hip_ctx *c, uint64_t cap);
+int ensure_loopq(rt_hip_ctx *c);
+uint64_t round_cap(uint64_t cap);
+
 int drain(rt_hip_ctx *c)
 {
     for (;;) {
+        bool grow = false;
         if (c->round_done && !c->batches.empty()) {
             HIP_TRY(hipEventSynchronize(c->round_done));
         } else {
@@ -653,6 +658,14 @@ int drain(rt_hip_ctx *c)
             const uint32_t *cnt = c->h_counters + i * c->cwords;
             if (batch_overflowed(cnt)) {
                 const uint32_t n = b.t1 - b.t0;
+                if (n <= 1 && c->auto_cap && c->cap < c->cap_limit) {
+                    /* one tile row needs more than the context has grown to yet (a wide frame with many samples a
+                     * pixel: 3.9 M samples a row at config 5): twice the queues, and again */
+                    grow = true;
+                    c->stats.overflow_retries++;
+                    c->todo.push_back(b);
+                    continue;
+                }
                 if (n <= 1) {
                     set_err("ray/node queues (%llu entries) overflow on a single 8-row tile row; raise the capacity",
                             (unsigned long long)c->cap);
@@ -680,6 +693,14 @@ int drain(rt_hip_ctx *c)
         c->batches.clear();
         if (c->todo.empty())
             return 0;
+        if (grow) { /* (the round is over: nothing of this context is in flight) */
+            const uint64_t twice = c->cap * 2u > c->cap_limit ? c->cap_limit : c->cap * 2u;
+            int rc = ensure_work(c, round_cap(twice));
+            if (!rc && jobs_path(c, c->job.stats))
+                rc = ensure_loopq(c);
+            if (rc)
+                return rc;
+        }
         int rc = enqueue_round(c);
         if (rc)
             return rc;

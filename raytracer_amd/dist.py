@@ -185,10 +185,13 @@ class FramePipeline:
             fg.gather(group=self.group, collective=self.collective, stream=comm.cuda_stream if self.cuda else None)
         self.gathered[k].record(comm)
 
-    def collect(self, i):
+    def collect(self, i, sizing=False):
+        """sizing=True: a frame rendered only so that its context sizes its queues (a context that sizes itself
+        renders its first frame of a shape in batches that may overflow and be rendered again): its gathered copy
+        is not looked at, and the retries are no error"""
         k = i % self.inflight
         stats = self.finish_fn(i, k)
-        if self.plan.world > 1 and stats is not None and getattr(stats, "overflow_retries", 0):
+        if self.plan.world > 1 and not sizing and stats is not None and getattr(stats, "overflow_retries", 0):
             raise RuntimeError("a batch of frame %d overflowed its queues and was rendered again after its rows had "
                                "been gathered: raise the context's capacity" % i)
         return stats

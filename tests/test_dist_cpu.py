@@ -135,13 +135,15 @@ def _pipeline_worker(rank, world, port, W, H, nframes, inflight, gather_stream, 
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("H,inflight,gather_stream", [(45, 2, "side"), (64, 3, "same"), (5, 2, "side")])
+@pytest.mark.parametrize("H,inflight,gather_stream", [(45, 2, "side"), (64, 3, "same"), (5, 2, "side"),
+                                                     (45, 6, "side"), (64, 6, "same")])   # six: bench.py's N > 1 default
 def test_frames_in_flight_through_the_shared_pipeline(tmp_path, H, inflight, gather_stream):
     """raytracer_amd.dist.FramePipeline - the submit / collect loop bench.py times - with two gloo ranks:
     several frames in flight, each rank rendering into ITS slice of the slot's gather buffer (the in-place
     all-gather), slots re-used frame after frame, a ragged last block (45 rows), a rank without any block
-    (5 rows over 2 ranks).  Every rank must see every frame complete and in order."""
-    world, W, nframes = 2, 40, 7
+    (5 rows over 2 ranks), and the six frames in flight bench.py keeps on more than one rank.  Every rank must see
+    every frame complete and in order."""
+    world, W, nframes = 2, 40, max(7, 2 * inflight + 3)   # every slot is used at least twice
     mp.spawn(_pipeline_worker, args=(world, _free_port(), W, H, nframes, inflight, gather_stream, str(tmp_path)),
              nprocs=world, join=True)
     for rank in range(world):

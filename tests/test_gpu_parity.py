@@ -925,6 +925,27 @@ def test_a_limit_on_the_queues_means_more_batches_not_other_pixels(torch_cuda, m
     ctx.close()
 
 
+def test_a_self_sizing_context_grows_for_one_wide_tile_row(torch_cuda, make_scene):
+    """An 8-row job of a wide frame with many samples a pixel (what a rank of config 5 renders block by block for
+    its instrumented pass): the context starts at 1 Mi entries, one tile row cannot be halved - it doubles its
+    queues and renders the row again, with the pixels and counters of a context that had the room at once."""
+    torch = torch_cuda
+    sc = make_scene("c5")
+    W, H, s, d = 4096, 8, 8, 6        # 2.1 M samples in the middle of the sphere cloud: more than a hit a sample
+    cam = rt.prepare_camera(sc, W, 2048, s, d)
+    frames = []
+    for cap in (1 << 24, 0):
+        ctx = rt.Context(queue_cap=cap)
+        ctx.upload(sc)
+        argb = torch.zeros((2048, W), dtype=torch.int32, device="cuda")
+        st = ctx.render_stats(cam, argb.data_ptr(), 0, 1600, H, 0)
+        frames.append((argb[1600:1600 + H].cpu().numpy(), st.shade_nodes, st.reflection_rays, st.transmission_rays))
+        if cap == 0:
+            assert st.overflow_retries >= 1 and st.batches == 1
+        ctx.close()
+    assert np.array_equal(frames[0][0], frames[1][0]) and frames[0][1:] == frames[1][1:]
+
+
 def test_tail_stream_changes_nothing(torch_cuda, make_scene):
     """rt_hip_ctx_set_tail_stream: the sparse levels, folds and resolve of every batch on a second stream.
     Same pixels, radiance bits and counters as on one stream - for a single batch, for a frame cut into
