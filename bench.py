@@ -207,6 +207,11 @@ def main():
                          "on the sphere clouds, c4 / c5s, where the tolerance build is NOT within that bar: rays graze "
                          "hundreds of spheres and one flipped hit is another picture of the pixel): every operation "
                          "rounded like the reference's x86 build (pixels bit-identical to the reference's)")
+    ap.add_argument("--graph", choices=["on", "off"], default="off",
+                    help="frames as HIP graphs (rt_hip_ctx_set_graph): one graph launch a frame instead of a dozen kernel "
+                         "launches, where every frame has a stream of its own. Off: on ROCm 7.2 the graph launch costs "
+                         "the host more than the launches it replaces (a rank of eight on config 3: submit 69 us a "
+                         "frame against 57, 0.1137 ms a frame either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-one-shot", action="store_true", help="skip the child processes that time the blocking raytrace() call")
     ap.add_argument("--no-generic", action="store_true", help="skip the short extra run with the generic kernels")
@@ -272,6 +277,7 @@ def main():
         c.upload(scene)
         c.set_numerics(numerics)
         c.set_launch_plan(args.launch_plan == "on")
+        c.set_graph(args.graph == "on")
         if tail is not None:
             c.set_tail_stream(tail.cuda_stream)
         ctxs.append(c)

@@ -159,6 +159,8 @@ typedef struct {
     uint32_t planned_launches, plan_builds;
     uint32_t work_mib;          /* MiB of device memory the context holds for queues, nodes and per-sample arrays */
     uint32_t reserved_;
+    /* frames of this render launched as a HIP graph, and graphs captured for them (rt_hip_ctx_set_graph) */
+    uint32_t graph_launches, graph_captures;
 } rt_hip_stats;
 
 /* ------------------------------------------------------------------------------------ */
@@ -359,6 +361,16 @@ void rt_hip_ctx_set_specialization(rt_hip_ctx *ctx, int enable);
  * refreshed every 8th render while the view keeps changing.  Big scenes (RT_PIPELINE_AUTO below) have no such
  * kernel and no plan.  No counterpart in the reference (its pixels are one serial loop, raytrace.c:746-792). */
 void rt_hip_ctx_set_launch_plan(rt_hip_ctx *ctx, int mode);
+
+/* HIP graph of a frame.  enable = 1: once a render's launches repeat - one image batch of the fused pipeline, on one
+ * stream of the caller's (not the null stream; no tail stream), the view, buffers and level counts of the last frame - they are captured from
+ * the stream once (hipStreamBeginCapture on the render's stream, thread-local mode) and every later frame is ONE
+ * hipGraphLaunch on it instead of a dozen kernel launches; a changed camera, scene, buffer or level count captures
+ * anew.  What a rank of a frame split over eight GPUs needs: there the host's 50 us of launches per frame, not the
+ * GPU, set the frame rate.  Same kernels, same pixels; stats.graph_launches / graph_captures count.  With
+ * rt_hip_ctx_set_timing on, every 8th frame is launched the plain way, between its events (k0_ms, k0_launches).
+ * Off by default.  No counterpart in the reference. */
+void rt_hip_ctx_set_graph(rt_hip_ctx *ctx, int enable);
 
 /* The host half of the launch plan, exported for tests (no GPU involved): the order rt_hip_finish builds from
  * wave_ticks[(tile row * block_columns + block column) * 4 + wave], the time each of a block's four waves took -

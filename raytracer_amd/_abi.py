@@ -105,7 +105,8 @@ class rt_hip_stats(C.Structure):
                 + [(n, _U64) for n in _STAT_U64_B]
                 + [("k0_ms", C.c_float), ("k0_launches", C.c_uint32), ("primary_rays_culled", _U64),
                    ("planned_launches", C.c_uint32), ("plan_builds", C.c_uint32),
-                   ("work_mib", C.c_uint32), ("reserved_", C.c_uint32)])
+                   ("work_mib", C.c_uint32), ("reserved_", C.c_uint32),
+                   ("graph_launches", C.c_uint32), ("graph_captures", C.c_uint32)])
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -174,6 +174,10 @@ class Context:
         fused multiply-adds, 1-ulp rcp / rsq / sqrt) - rt_hip_ctx_set_numerics"""
         check(load().rt_hip_ctx_set_numerics(self._h, int(mode)), "rt_hip_ctx_set_numerics")
 
+    def set_graph(self, on):
+        """frames whose launches repeat are captured once and replayed as one HIP graph launch (rt_hip_ctx_set_graph)"""
+        load().rt_hip_ctx_set_graph(self._h, int(bool(on)))
+
     def set_launch_plan(self, on):
         """False: k_primary's blocks always in raster order; True (the default): slowest first, from the times the
         tiles of the last frame of this shape took (rt_hip_ctx_set_launch_plan)"""

@@ -155,6 +155,17 @@ struct rt_hip_ctx {
     std::vector<char> plan_view_now;
     bool plan_use = false, plan_record = false; /* this frame: follow d_plan / record wave times */
     uint64_t scene_serial = 0;     /* counts the uploads that changed the scene */
+    /*
+     * HIP graph of a frame (rt_hip_ctx_set_graph).  A frame of the fused pipeline is a dozen launches, 50 us of host
+     * time - more than the GPU needs for a rank's share of a frame split over eight GPUs.  Once the launches of a
+     * frame repeat (same view, buffers, queue sizes, level counts), they are captured from the stream once and
+     * replayed as ONE graph launch; anything that changes a launch parameter captures anew.
+     */
+    int use_graph = 0;
+    bool capturing = false;  /* enqueue_batch is being recorded, not run: no timing events */
+    uint32_t graph_frame = 0; /* with timing on, every 8th frame is launched the plain way and timed */
+    hipGraphExec_t graph_exec = nullptr;
+    std::vector<uint64_t> graph_key; /* every launch parameter of the captured frame */
 };
 constexpr uint32_t kPlanRefresh = 8;
 
@@ -347,7 +358,7 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
     if (cut && c->tail_pending) /* the queues and node pool are shared with this context's previous batch */
         HIP_TRY(hipStreamWaitEvent(st, c->tail_done, 0));
     /* the counter block is zero: k_publish at the end of its last use left it so */
-    const bool timed = c->timing && !stats;
+    const bool timed = c->timing && !stats && !c->capturing;
     if (timed) {
         hipEvent_t e0, e1;
         HIP_TRY(hipEventCreate(&e0));
@@ -588,6 +599,69 @@ void accumulate(rt_hip_stats &s, const uint32_t *cnt, uint32_t levels)
     s.primary_rays_culled += st[ST_K0_CULLED];
 }
 
+/* A frame that is one batch of the fused pipeline on one stream, uninstrumented, its level counts known: as a graph.
+ * The key lists what the launches depend on; equal key = the captured graph is this frame's. */
+int enqueue_batch_graphed(rt_hip_ctx *c, const Batch &b, bool stats)
+{
+    const bool whole = b.t0 == 0 && b.t1 == c->job.ntiles && b.slot == 0;
+    if (!c->use_graph || !c->stream /* (the null stream cannot be captured) */ || stats || !whole || (c->timing && (c->graph_frame++ & 7u) == 0u) || !c->seen_valid || c->plan_record || c->early_alias ||
+        (c->tail_stream && c->tail_stream != c->stream) || jobs_path(c, stats))
+        return enqueue_batch(c, b, stats);
+    std::vector<uint64_t> key;
+    key.reserve(96);
+    auto bytes = [&](const void *p, size_t n) {
+        const size_t at = key.size();
+        key.resize(at + (n + 7) / 8, 0);
+        memcpy(key.data() + at, p, n);
+    };
+    bytes(&c->C, sizeof c->C);
+    const Job &j = c->job;
+    const uint64_t rest[] = {c->scene_serial, (uint64_t)c->numerics, (uint64_t)c->shading, j.interleaved ? 1u : 0u,
+                             ((uint64_t)j.row0 << 32) | j.nrows, ((uint64_t)j.phase << 32) | j.nphases, j.ntiles,
+                             (uint64_t)(uintptr_t)c->d_argb, (uint64_t)(uintptr_t)c->d_rad, (uint64_t)(uintptr_t)c->W.base,
+                             c->W.stride, c->W.cap, (uint64_t)(uintptr_t)c->pixAcc, (uint64_t)(uintptr_t)c->roots,
+                             (uint64_t)(uintptr_t)c->tile_done, (uint64_t)(uintptr_t)c->d_counters,
+                             (uint64_t)(uintptr_t)c->scene_blob, (uint64_t)(uintptr_t)(c->plan_use ? c->d_plan : nullptr),
+                             c->plan_use ? c->plan_len : 0u, (uint64_t)c->no_shape, (uint64_t)c->cwords,
+                             (uint64_t)c->stats.plan_builds};
+    bytes(rest, sizeof rest);
+    bytes(c->seen_hits, sizeof c->seen_hits);
+    bytes(c->seen_nodes, sizeof c->seen_nodes);
+    if (!c->graph_exec || key != c->graph_key) {
+        if (c->graph_exec) {
+            (void)hipGraphExecDestroy(c->graph_exec);
+            c->graph_exec = nullptr;
+        }
+        hipGraph_t g = nullptr;
+        HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        c->capturing = true;
+        const int rc = enqueue_batch(c, b, stats);
+        c->capturing = false;
+        const hipError_t e = hipStreamEndCapture(c->stream, &g);
+        if (rc || e != hipSuccess || !g) {
+            if (g)
+                (void)hipGraphDestroy(g);
+            (void)hipGetLastError();
+            if (rc)
+                return rc;
+            set_err("capturing the frame's launches failed: %s", hipGetErrorString(e));
+            return -(int)e;
+        }
+        const hipError_t ei = hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (ei != hipSuccess) {
+            c->graph_exec = nullptr;
+            set_err("instantiating the frame's graph failed: %s", hipGetErrorString(ei));
+            return -(int)ei;
+        }
+        c->graph_key.swap(key);
+        c->stats.graph_captures++;
+    }
+    HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
+    c->stats.graph_launches++;
+    return 0;
+}
+
 /* Enqueue up to kMaxBatches batches of the work list (one counter slot each) and the copy of
  * their counters to the pinned mirror.  Asynchronous. */
 int enqueue_round(rt_hip_ctx *c)
@@ -598,7 +672,7 @@ int enqueue_round(rt_hip_ctx *c)
         Batch b = c->todo.back();
         c->todo.pop_back();
         b.slot = (uint32_t)c->batches.size();
-        int rc = enqueue_batch(c, b, c->job.stats);
+        int rc = enqueue_batch_graphed(c, b, c->job.stats);
         if (rc)
             return rc;
         c->batches.push_back(b);
@@ -1002,6 +1076,7 @@ void rt_hip_ctx_destroy(rt_hip_ctx *c)
     }
     drop_events(c);
     if (c->round_done) (void)hipEventDestroy(c->round_done);
+    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     if (c->early_from) (void)hipEventDestroy(c->early_from);
     if (c->early_done) (void)hipEventDestroy(c->early_done);
     if (c->early_stream) (void)hipStreamDestroy(c->early_stream);
@@ -1047,6 +1122,12 @@ int rt_hip_ctx_set_pipeline(rt_hip_ctx *c, int mode)
         c->seen_valid = false; /* (the two pipelines count their tree nodes differently) */
     c->no_jobs = mode == RT_PIPELINE_FUSED;
     return 0;
+}
+
+void rt_hip_ctx_set_graph(rt_hip_ctx *c, int enable)
+{
+    if (c)
+        c->use_graph = enable != 0;
 }
 
 void rt_hip_ctx_set_launch_plan(rt_hip_ctx *c, int enable)

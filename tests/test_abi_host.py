@@ -52,14 +52,14 @@ def test_layouts_match_reference_x86_64():
 
 
 def test_header_compiles_as_c_and_cpp(tmp_path):
-    src = '#include "rt_hip.h"\nint main(void){return (int)sizeof(rt_hip_stats) == 296 ? 0 : 1;}\n'
+    src = '#include "rt_hip.h"\nint main(void){return (int)sizeof(rt_hip_stats) == 304 ? 0 : 1;}\n'
     for comp, ext in (("gcc", "c"), ("g++", "cpp")):
         f = tmp_path / f"t.{ext}"
         f.write_text(src)
         exe = tmp_path / f"t_{ext}"
         subprocess.check_call([comp, "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(f), "-o", str(exe)])
         assert subprocess.call([str(exe)]) == 0
-    assert C.sizeof(A.rt_hip_stats) == 296
+    assert C.sizeof(A.rt_hip_stats) == 304
 
 
 def test_builtin_scene_equals_the_reference_parse_scene(golden):

@@ -224,3 +224,59 @@ def test_random_scenes_planned_and_through_either_pipeline(torch_cuda):
                 assert np.array_equal(r.view(np.uint32), first.view(np.uint32)), what
         ctx.close()
         plain.close()
+
+
+def test_frames_as_graphs_show_the_same_pixels(torch_cuda):
+    """rt_hip_ctx_set_graph: once the launches of a frame repeat they are captured and replayed as one graph launch.
+    Same pixels and counters as the plain launches; one capture for a run of equal frames, a new one when the view
+    changes, the plain way again for the first frames of a new shape and - sampled - with timing on."""
+    torch = torch_cuda
+    sc = rt.Scene.builtin()
+    W, H, s, d = 640, 360, 2, 8
+    cam = rt.prepare_camera(sc, W, H, s, d)
+    plain = rt.Context()
+    plain.upload(sc)
+    want, want_rad, st0 = render_dev(torch, plain, cam)
+    g = rt.Context()
+    g.upload(sc)
+    g.set_graph(True)
+    stream = torch.cuda.Stream()
+    argb = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    rad = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+
+    def frame(c):
+        argb.zero_(); rad.zero_()
+        torch.cuda.synchronize()
+        g.render_rows(c, argb.data_ptr(), rad.data_ptr(), 0, H, stream.cuda_stream)
+        st = g.finish()
+        return argb.cpu().numpy().view(np.uint32), rad.cpu().numpy(), st
+
+    launches = captures = 0
+    for i in range(8):
+        a, r, st = frame(cam)
+        assert np.array_equal(a, want) and np.array_equal(r.view(np.uint32), want_rad.view(np.uint32)), i
+        assert (st.shade_nodes, st.reflection_rays, st.transmission_rays) == (st0.shade_nodes, st0.reflection_rays, st0.transmission_rays)
+        launches += st.graph_launches
+        captures += st.graph_captures
+    assert launches >= 4 and 1 <= captures <= 2, (launches, captures)   # (the launch plan's arrival changes the launches once)
+    # another view: the plain way while its level counts are unknown, then a graph of its own
+    cam2 = rt.prepare_camera(sc, W, H, s, 5)
+    want2, want2_rad, _ = render_dev(torch, plain, cam2)
+    seen = []
+    for i in range(5):
+        a, r, st = frame(cam2)
+        assert np.array_equal(a, want2) and np.array_equal(r.view(np.uint32), want2_rad.view(np.uint32)), i
+        seen.append((st.graph_launches, st.graph_captures))
+    assert seen[0] == (0, 0) and seen[-1] == (1, 0) and sum(c for _, c in seen) <= 2, seen
+    # timing on: every 8th frame goes the plain way between its events
+    g.set_timing(True)
+    timed = 0
+    for i in range(16):
+        a, r, st = frame(cam2)
+        assert np.array_equal(a, want2)
+        assert st.graph_launches + st.k0_launches == 1
+        timed += st.k0_launches
+    assert timed == 2
+    g.close()
+    plain.close()
