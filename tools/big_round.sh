@@ -13,7 +13,7 @@ for c in ("c5s","c4"):
 PY
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for c in c5s c4; do
-  timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${tag}_trace_$c -- python3 bench.py --config $c --numerics exact --steps 3 --warmup 1 --no-cpu-baseline --no-generic --shared-stream --inflight 1 --tail-stream off > gpurun_out/${tag}_trace_$c.log 2>&1 || { tail -5 gpurun_out/${tag}_trace_$c.log; exit 1; }
+  timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${tag}_trace_$c -- python3 bench.py --config $c --numerics exact --steps 3 --warmup 1 --no-cpu-baseline --no-one-shot --no-generic --shared-stream --inflight 1 --tail-stream off > gpurun_out/${tag}_trace_$c.log 2>&1 || { tail -5 gpurun_out/${tag}_trace_$c.log; exit 1; }
   echo "== $c"; python3 tools/big_trace.py gpurun_out/${tag}_trace_$c
 done
 if [ -f raytracer_amd/librt_hip_b.so ]; then

@@ -27,4 +27,10 @@ for name, f in (("shadow", ("k0_sphere_tests", "k0_sphere_hits", "k0_polygon_tes
     blocks, lanes, listed, tests = (getattr(st, k) for k in f)
     print(f"{cfg} {name}: sphere tests {tests:.3e} (lane level), distance blocks run {blocks:.3e} with {lanes / max(blocks, 1):.1f} lanes each, "
           f"lane-iterations in a listed cell {listed:.3e}")
+if os.environ.get("JOBS_TIMES"):  # a -DRT_JOBS_COUNT -DRT_JOBS_TIMES build: the second group of slots holds ticks per phase
+    for name, f in (("shadow", ("k0_sphere_tests", "k0_sphere_hits", "k0_polygon_tests", "k0_polygon_rej_parallel")),
+                    ("child", ("k0_polygon_rej_behind", "k0_polygon_full", "k0_lights_lit", "k0_nodes_sphere"))):
+        fl, so, bu, stp = (getattr(st, k) for k in f)
+        tot = max(fl + so + bu + stp, 1)
+        print(f"{cfg} {name}: wave time by phase: results + refill {fl / tot:.2f}, sorting out jobs {so / tot:.2f}, building rays {bu / tot:.2f}, walking {stp / tot:.2f}")
 print("rays", st.primary_rays, st.shadow_rays, st.reflection_rays, st.transmission_rays, "shade nodes", st.shade_nodes)

@@ -8,7 +8,7 @@ tag=${1:-r03}; shift
 cfgs=${@:-c4 c5s}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for cfg in $cfgs; do
-  cmd="bench.py --config $cfg --numerics exact --steps 3 --warmup 1 --no-cpu-baseline --no-generic --shared-stream --inflight 1 --tail-stream off"
+  cmd="bench.py --config $cfg --numerics exact --steps 3 --warmup 1 --no-cpu-baseline --no-one-shot --no-generic --shared-stream --inflight 1 --tail-stream off"
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_$cfg -- python3 $cmd > gpurun_out/prof_${tag}_$cfg.log 2>&1 || { tail -5 gpurun_out/prof_${tag}_$cfg.log; exit 1; }
   n=0
   for pass in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
