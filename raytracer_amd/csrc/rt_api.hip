@@ -241,7 +241,7 @@ bool jobs_path(const rt_hip_ctx *c, bool stats)
 {
     static const bool off = getenv("RT_HIP_NO_JOBS") != nullptr; /* development: the fused kernels for every scene */
     return !off && !c->no_jobs && c->S.grid != nullptr && (c->S.lgrid != nullptr || c->S.nLights == 0u) && !stats && c->shading == RT_SHADE_PHONG &&
-           c->S.nLights <= RT_JOBS_MAX_LIGHTS;
+           c->S.nLights <= RT_JOBS_MAX_LIGHTS && c->S.nSph <= RT_CHUNK_MAX_SPHERES;
 }
 
 int ensure_level0(rt_hip_ctx *c, size_t npix, size_t spp2)
@@ -1405,29 +1405,43 @@ void build_grid(const std::vector<float4> &sph, const rt_scene *sc, const std::v
                     }
         }
         if (pass == 1) {
-            /* ... and the cells once more as 128-byte records with their spheres inline (CellRec) */
+            /* ... and the cells once more as 64-byte chunks with their spheres inline (CellChunk) */
             const size_t lists = G.words + cells + 1 + items.size();
-            G.rec_words = (uint32_t)((lists + 3u) & ~(size_t)3u);
+            const bool chunked = n <= RT_CHUNK_MAX_SPHERES;
+            G.rec_words = chunked ? (uint32_t)((lists + 15u) & ~(size_t)15u) : 0u;
             G.pad_[0] = G.pad_[1] = G.pad_[2] = 0u;
-            words.assign((size_t)G.rec_words + cells * (sizeof(CellRec) / sizeof(uint32_t)), 0u);
+            std::vector<CellChunk> chunks;
+            if (chunked) {
+                chunks.assign(cells, CellChunk{});
+                auto fill_chunk = [&](CellChunk &ck, uint32_t beg, uint32_t cnt) { /* up to three of the items from beg on */
+                    uint32_t k[RT_CHUNK_SPHERES] = {0u, 0u, 0u};
+                    for (uint32_t u = 0; u < cnt && u < RT_CHUNK_SPHERES; ++u) {
+                        k[u] = items[beg + u];
+                        ck.sph[u] = sph[k[u]];
+                    }
+                    ck.idx_lo = k[0] | (k[1] << 21);
+                    ck.idx_hi = (k[1] >> 11) | (k[2] << 10);
+                };
+                for (size_t ci = 0; ci < cells; ++ci) {
+                    const uint32_t beg = count[ci], cnt = count[ci + 1] - beg;
+                    chunks[ci].count = cnt;
+                    fill_chunk(chunks[ci], beg, cnt);
+                    if (cnt > RT_CHUNK_SPHERES) {
+                        chunks[ci].next = (uint32_t)chunks.size();
+                        for (uint32_t u = RT_CHUNK_SPHERES; u < cnt; u += RT_CHUNK_SPHERES) {
+                            chunks.push_back(CellChunk{});
+                            fill_chunk(chunks.back(), beg + u, cnt - u);
+                        }
+                    }
+                }
+            }
+            words.assign(chunked ? (size_t)G.rec_words + chunks.size() * (sizeof(CellChunk) / sizeof(uint32_t)) : lists, 0u);
             memcpy(words.data(), &G, sizeof G);
             memcpy(words.data() + G.words, count.data(), (cells + 1) * sizeof(uint32_t));
             if (!items.empty())
                 memcpy(words.data() + G.words + cells + 1, items.data(), items.size() * sizeof(uint32_t));
-            CellRec *rec = (CellRec *)(words.data() + G.rec_words);
-            for (size_t ci = 0; ci < cells; ++ci) {
-                const uint32_t beg = count[ci], cnt = count[ci + 1] - beg;
-                if (cnt <= RT_CELL_INLINE) {
-                    rec[ci].count = cnt;
-                    for (uint32_t u = 0; u < cnt; ++u) {
-                        rec[ci].idx[u] = items[beg + u];
-                        rec[ci].sph[u] = sph[items[beg + u]];
-                    }
-                } else {
-                    rec[ci].count = cnt | RT_CELL_LISTED;
-                    rec[ci].idx[0] = beg;
-                }
-            }
+            if (!chunks.empty())
+                memcpy(words.data() + G.rec_words, chunks.data(), chunks.size() * sizeof(CellChunk));
         }
     }
     grown.resize(n);

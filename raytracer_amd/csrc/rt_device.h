@@ -80,26 +80,31 @@ struct GridHeader {
     uint32_t words;  /* size of this header in uint32_t  */
     float centre[3]; /* of the box                       */
     float origin_reach2; /* a ray walks the grid only if its origin is within sqrt(this) of the centre */
-    uint32_t rec_words;  /* where the cell records start: words from the grid's base, a multiple of 4 */
+    uint32_t rec_words;  /* where the cell chunks start: words from the grid's base, a multiple of 16; 0: none (too many spheres) */
     uint32_t pad_[3];
 };
-/* The same cells once more, one 128-byte record each, for the walks of the job pipeline (rt_jobs.inc): a lane gets a
- * cell's spheres with ONE round trip instead of three dependent ones (cellStart -> items -> sph), and every walking
- * lane of a wave does the same thing per cell.  (Six spheres: the cells list the spheres GROWN by what the
- * reference's test accepts beyond geometry at the grid's reach - config 5's 0.15-radius spheres count as 0.35 - so a
- * cell holds four on average; with three inline slots four fifths of the walk's time went into the fuller cells'
- * lists, one sphere per iteration.)
- *   count <= 6: the cell's spheres are idx[0 .. count) / sph[0 .. count) (centre, r*r: DevScene::sph's words)
- *   else      : bit 31 set, count & 0x7fffffff entries of the grid's item list from idx[0] on */
-#define RT_CELL_INLINE 6u
-struct CellRec {
+/* The same cells once more as 64-byte CHUNKS of up to three spheres, for the walks of the job pipeline (rt_jobs.inc):
+ * a lane gets a chunk with ONE round trip instead of three dependent ones (cellStart -> items -> sph), every walking
+ * lane of a wave does the same thing per iteration - one chunk, three tests - and the address of the next chunk is
+ * known before the tests begin, so it is fetched beside them.
+ * History: three inline spheres in a 64-byte record and the fuller cells' lists one sphere per iteration - four
+ * fifths of the walk went into those lists (the cells list the spheres GROWN by what the reference's test accepts
+ * beyond geometry at the grid's reach: config 5's 0.15-radius spheres count as 0.35, four to a cell); six spheres
+ * in a 128-byte record - every iteration ran six test blocks for the one lane in a fuller cell (config 4: 2.2
+ * spheres per occupied cell, 13 % of them hold more than three), and a walking lane's eight 16-byte loads each cost
+ * the CU's vector memory pipe a cache-line look-up per lane.
+ *   chunk c < cells: the first chunk of cell c: count = the cell's spheres, the first three inline; if count > 3 the
+ *   others follow from chunk `next` on, three to a chunk, one behind the other (their count and next are 0).
+ *   Sphere indices: 21 bits each (RT_CHUNK_MAX_SPHERES), i0 | i1 << 21 in idx_lo, i1 >> 11 | i2 << 10 in idx_hi. */
+#define RT_CHUNK_SPHERES 3u
+#define RT_CHUNK_MAX_SPHERES (1u << 21)
+struct CellChunk {
     uint32_t count;
-    uint32_t idx[RT_CELL_INLINE];
-    uint32_t pad_;
-    float4 sph[RT_CELL_INLINE];
+    uint32_t idx_lo, idx_hi;
+    uint32_t next;
+    float4 sph[RT_CHUNK_SPHERES]; /* (centre, r*r): DevScene::sph's words */
 };
-static_assert(sizeof(CellRec) == 128, "cell records are two cache-line halves");
-#define RT_CELL_LISTED 0x80000000u
+static_assert(sizeof(CellChunk) == 64, "a chunk is half a cache line");
 
 /*
  * Shadow rays end at a light: every sphere such a ray can meet lies in a narrow cone around the ray as seen FROM

@@ -52,8 +52,8 @@ for d in sorted(glob.glob(f"gpurun_out/pmc_{tag}_{cfg}_*/")):
 print(f"# {cfg}, exact build, last frame, one frame at a time (tools/profile_big_r03.sh {tag}); us = kernel-trace duration;")
 print("# busy = 2 x VALU insts / (1024 SIMDs x elapsed cycles); lanes = active lanes per VALU inst / 64; w/simd = resident waves per SIMD;")
 print("# wait = share of wave cycles parked in s_waitcnt; stall = share in issue stalls; L2hit = TCC hit / (hit + miss); L1miss = TCP->TCC reads / TCP accesses;")
-print("# MBrd / MBwr = HBM bytes (2 x FETCH_SIZE, WRITE_SIZE)")
-print(f"{'kernel':34s} {'us':>9s} {'blocks':>7s} {'vgpr':>4s} {'waves':>8s} {'valu_M':>8s} {'busy':>5s} {'lanes':>5s} {'w/simd':>6s} {'wait':>5s} {'stall':>5s} {'vmemrd_M':>8s} {'L2hit':>5s} {'L1miss':>6s} {'MBrd':>7s} {'MBwr':>7s}")
+print("# MBrd / MBwr = HBM bytes (2 x FETCH_SIZE, WRITE_SIZE); issue = (2 x VALU + SALU + SMEM + LDS + branch + VMEM insts) / (1024 SIMDs x elapsed cycles)")
+print(f"{'kernel':34s} {'us':>9s} {'blocks':>7s} {'vgpr':>4s} {'waves':>8s} {'valu_M':>8s} {'busy':>5s} {'lanes':>5s} {'w/simd':>6s} {'wait':>5s} {'stall':>5s} {'vmemrd_M':>8s} {'L2hit':>5s} {'L1miss':>6s} {'MBrd':>7s} {'MBwr':>7s} {'salu_M':>8s} {'brnch_M':>8s} {'lds_M':>7s} {'issue':>5s}")
 tot = 0.0
 for i, lab in enumerate(labels):
     c = ctr[i]
@@ -67,6 +67,9 @@ for i, lab in enumerate(labels):
     l2 = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) if (c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0)) else None
     l1 = c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"] if c.get("TCP_TOTAL_CACHE_ACCESSES_sum") else None
     tot += dur[i]
+    # the SIMDs' issue slots in use by the model of DESIGN (a vector instruction two cycles, every other kind one)
+    issue = (2 * c["SQ_INSTS_VALU"] + c["SQ_INSTS_SALU"] + c["SQ_INSTS_SMEM"] + c["SQ_INSTS_LDS"] + c["SQ_INSTS_BRANCH"]
+             + c["SQ_INSTS_VMEM_RD"] + c["SQ_INSTS_VMEM_WR"]) / (1024 * cyc) if cyc else None
     print(f"{lab:34s} {dur[i]:9.1f} {grid[i]:7d} {vg[i]:>4s} {c.get('SQ_WAVES', 0):8.0f} {c.get('SQ_INSTS_VALU', 0) / 1e6:8.2f} {f(busy)} {f(lanes)} {f(wps):>6s} {f(wait)} {f(stall)} "
-          f"{c.get('SQ_INSTS_VMEM_RD', 0) / 1e6:8.2f} {f(l2)} {f(l1):>6s} {c.get('FETCH_SIZE', 0) * 2 / 1024:7.1f} {c.get('WRITE_SIZE', 0) / 1024:7.1f}")
+          f"{c.get('SQ_INSTS_VMEM_RD', 0) / 1e6:8.2f} {f(l2)} {f(l1):>6s} {c.get('FETCH_SIZE', 0) * 2 / 1024:7.1f} {c.get('WRITE_SIZE', 0) / 1024:7.1f} {c.get('SQ_INSTS_SALU', 0) / 1e6:8.2f} {c.get('SQ_INSTS_BRANCH', 0) / 1e6:8.2f} {c.get('SQ_INSTS_LDS', 0) / 1e6:7.2f} {f(issue)}")
 print(f"# sum of kernel durations {tot / 1e3:.2f} ms")
