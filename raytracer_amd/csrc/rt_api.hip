@@ -1555,18 +1555,12 @@ void build_light_grids(const std::vector<float4> &sph, const std::vector<double>
     H.ncell = (uint32_t)ncell;
     H.off_cells = (uint32_t)(sizeof H / sizeof(uint32_t));
     H.off_gstart = H.off_cells + (uint32_t)count.size();
-    H.off_idx = 0; /* (items are 32-byte records now: off_sph) */
-    H.off_sph = (H.off_gstart + nL + 1 + 3u) & ~3u;
-    H.nitems = nitems;
-    H.pad_ = 0;
-    words.assign((size_t)H.off_sph + (size_t)nitems * 8u, 0u);
-    memcpy(words.data(), &H, sizeof H);
-    memcpy(words.data() + H.off_cells, count.data(), count.size() * sizeof(uint32_t));
-    memcpy(words.data() + H.off_gstart, gcount.data(), gcount.size() * sizeof(uint32_t));
+    H.off_idx = 0;
     /* an item: (centre, r*r), (bits of the sphere's index, key, -, -).  key = distance from the light at which the
      * grown ball begins: a shadow ray that starts `mag` from the light cannot meet a sphere whose key exceeds mag,
      * and a cell's list is sorted by key, so its scan ends there.  The global lists carry key 0. */
-    float4 *item = (float4 *)(words.data() + H.off_sph);
+    std::vector<float4> item_store((size_t)nitems * 2u);
+    float4 *item = item_store.data();
     std::vector<uint32_t> fill(count.begin(), count.end() - 1);
     std::vector<float> key(n);
     for (uint32_t l = 0; l < nL; ++l) {
@@ -1598,6 +1592,45 @@ void build_light_grids(const std::vector<float4> &sph, const std::vector<double>
             std::stable_sort(first, first + (e0 - b0), [](const It &x, const It &y) { return x.b.y < y.b.y; });
         }
     }
+    /* ... and every list as 64-byte chunks of three items (LightChunk): the tables then count chunks */
+    std::vector<LightChunk> chunks;
+    chunks.reserve((size_t)nitems / 2u + count.size());
+    auto emit = [&](uint32_t b0, uint32_t e0) {
+        for (uint32_t i = b0; i < e0; i += RT_CHUNK_SPHERES) {
+            LightChunk ck{};
+            uint32_t k[RT_CHUNK_SPHERES] = {0u, 0u, 0u}, kb[RT_CHUNK_SPHERES] = {0x7F80u, 0x7F80u, 0x7F80u}; /* no item: key +inf */
+            for (uint32_t u = 0; u < RT_CHUNK_SPHERES && i + u < e0; ++u) {
+                ck.sph[u] = item[2 * (size_t)(i + u)];
+                k[u] = __builtin_bit_cast(uint32_t, item[2 * (size_t)(i + u) + 1].x);
+                kb[u] = __builtin_bit_cast(uint32_t, item[2 * (size_t)(i + u) + 1].y) >> 16; /* (keys are >= 0: cut off = rounded down) */
+            }
+            ck.idx_lo = k[0] | (k[1] << 21);
+            ck.idx_hi = (k[1] >> 11) | (k[2] << 10);
+            ck.keys01 = kb[0] | (kb[1] << 16);
+            ck.key2 = kb[2];
+            chunks.push_back(ck);
+        }
+    };
+    std::vector<uint32_t> cstart(count.size()), gstart(nL + 1);
+    for (size_t ci = 0; ci + 1 < count.size(); ++ci) {
+        cstart[ci] = (uint32_t)chunks.size();
+        emit(count[ci], count[ci + 1]);
+    }
+    cstart[count.size() - 1] = (uint32_t)chunks.size();
+    for (uint32_t l = 0; l < nL; ++l) {
+        gstart[l] = (uint32_t)chunks.size();
+        emit(gcount[l], gcount[l + 1]);
+    }
+    gstart[nL] = (uint32_t)chunks.size();
+    H.off_sph = (H.off_gstart + nL + 1 + 15u) & ~15u;
+    H.nitems = (uint32_t)chunks.size();
+    H.pad_ = 0;
+    words.assign((size_t)H.off_sph + chunks.size() * (sizeof(LightChunk) / sizeof(uint32_t)), 0u);
+    memcpy(words.data(), &H, sizeof H);
+    memcpy(words.data() + H.off_cells, cstart.data(), cstart.size() * sizeof(uint32_t));
+    memcpy(words.data() + H.off_gstart, gstart.data(), gstart.size() * sizeof(uint32_t));
+    if (!chunks.empty())
+        memcpy(words.data() + H.off_sph, chunks.data(), chunks.size() * sizeof(LightChunk));
 }
 } // namespace
 

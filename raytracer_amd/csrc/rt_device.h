@@ -115,10 +115,12 @@ static_assert(sizeof(CellChunk) == 64, "a chunk is half a cache line");
  * any-hit search is then ONE cell lookup and a scan of that cell's list and the global list - no walk.  Built by
  * rt_hip_scene_upload (rt_api.hip, build_light_grids); the same exclusions as the grid: direction of unit length,
  * origin within the grid's reach.
- *   words: LightGridHeader | cellStart[nLights * 6 * res * res + 1] | gstart[nLights + 1] | item[nitems], 32 bytes
- *          each: (centre, r*r), (bits of the sphere's index, key, -, -); key = the distance from the light at which
- *          the grown ball begins, a cell's list sorted by it (a ray that starts nearer the light than that cannot
- *          meet the sphere: the scan of the cell's list ends there).  Cell lists first, the global lists behind them.
+ *   words: LightGridHeader | cellStart[nLights * 6 * res * res + 1] | gstart[nLights + 1] | chunk[nitems], 64 bytes
+ *          each (LightChunk): up to three spheres of a list - (centre, r*r), the sphere's index (21 bits, packed as
+ *          in CellChunk) and its key as the upper half of a float, cut off (+inf: no sphere); key = the distance from
+ *          the light at which the grown ball begins, a cell's list sorted by it (a ray that starts nearer the light
+ *          than that cannot meet the sphere: the scan of the cell's list ends there; cutting a key off only makes it
+ *          smaller).  cellStart and gstart count chunks.  Cell lists first, the global lists (key 0) behind them.
  * cell of direction u (from the light): m = axis of the largest |u|, face = 2 m + (u[m] < 0),
  *   (a, b) = the other two components in axis order / |u[m]|, (ia, ib) = floor((a + 1) / 2 * res) clamped,
  *   cell = (face * res + ib) * res + ia.
@@ -126,8 +128,14 @@ static_assert(sizeof(CellChunk) == 64, "a chunk is half a cache line");
 struct LightGridHeader {
     uint32_t res, ncell;     /* ncell = 6 * res * res, cells per light */
     uint32_t off_cells, off_gstart, off_idx, off_sph; /* word offsets from the blob's base (off_sph a multiple of 4) */
-    uint32_t nitems, pad_;
+    uint32_t nitems, pad_; /* nitems: chunks */
 };
+struct LightChunk {
+    uint32_t idx_lo, idx_hi; /* i0 | i1 << 21, i1 >> 11 | i2 << 10 */
+    uint32_t keys01, key2;   /* key0 | key1 << 16, key2: upper halves of floats */
+    float4 sph[RT_CHUNK_SPHERES];
+};
+static_assert(sizeof(LightChunk) == 64, "a chunk is half a cache line");
 
 /* fields of an object record in DevScene::tab */
 enum {
