@@ -74,6 +74,7 @@ CONFIGS = {
     "c3": (None, 3840, 2160, 4, 8, 60, 10),
     "c4": ((0xC0FFEE04, 1024, 4, 1, 0), 3840, 2160, 4, 8, 6, 2),
     "c5s": ((0xC0FFEE05, 16384, 0, 8, 1), 1920, 1080, 2, 16, 4, 1),
+    "syn64": ((0xC0FFEE64, 64, 4, 1, 0), 1920, 1080, 4, 8, 30, 5),   # a small scene that is NOT the reference's: 64 spheres, 4 quads
     "c5": ((0xC0FFEE05, 16384, 0, 8, 1), 7680, 4320, 8, 16, 2, 1),   # BASELINE config 5 at full size: a job for 8 GPUs
 }
 
@@ -161,6 +162,44 @@ def cpu_baseline(sc, builtin, W, H, sqrt_spp, depth):
                       f"oracle/rt_oracle.c -O2, {total:.2f} s"}
 
 
+def small_scene_line(dev, numerics, numerics_name, cfg="syn64", frames=20):
+    """A small scene that is NOT the reference's (64 spheres, 4 quads, one light at 1080p x 16, depth 8), one frame at
+    a time, with kernels compiled at run time for its counts: k_primary's time and its reference-equivalent FLOP rate."""
+    scene_args, W, H, sqrt_spp, depth, _, _ = CONFIGS[cfg]
+    sc = rt.Scene.synthetic(*scene_args)
+    cam = rt.prepare_camera(sc, W, H, sqrt_spp, depth)
+    g = rt.Context(device=dev.index)
+    g.upload(sc)
+    g.set_numerics(numerics)
+    g.set_jit(rt.JIT_NOW)
+    frame = torch.zeros((H, W), dtype=torch.int32, device=dev)
+    st_alg = g.render_stats(cam, frame.data_ptr(), 0, 0, H, 0).as_dict()
+    flops = algorithmic_flops_k0(st_alg, W * H * sqrt_spp * sqrt_spp)
+    ms, n, rays, t0 = 0.0, 0, 0, 0.0
+    for i in range(6 + frames):
+        if i == 6:
+            g.set_timing(True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        g.render_rows(cam, frame.data_ptr(), 0, 0, H, 0)
+        st = g.finish()
+        if i >= 6:
+            ms += st.k0_ms
+            n += st.k0_launches
+            rays += st.primary_rays + st.shadow_rays + st.reflection_rays + st.transmission_rays
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    state, sec, _ = g.jit_status()
+    g.close()
+    kms = ms / max(n, 1)
+    return {"workload": f"{cfg}: synthetic scene (seed {scene_args[0]:#x}: {scene_args[1]} spheres, {scene_args[2]} quads, "
+                        f"{scene_args[3]} light) {W}x{H}, sqrtSpp {sqrt_spp}, depth {depth}; {frames} frames, one at a time",
+            "numerics": numerics_name, "ms_per_frame": dt / frames * 1e3, "mrays_per_s": rays / dt / 1e6,
+            "k_primary_ms": kms, "algorithmic_flop_per_launch": flops,
+            "frac": flops / (kms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS if kms else 0.0,
+            "run_time_kernels": {"state": state, "compile_seconds": sec}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,9 +251,15 @@ def main():
                          "launches, where every frame has a stream of its own. Off: on ROCm 7.2 the graph launch costs "
                          "the host more than the launches it replaces (a rank of eight on config 3: submit 69 us a "
                          "frame against 57, 0.1137 ms a frame either way)")
+    ap.add_argument("--jit", choices=["auto", "now", "off"], default=None,
+                    help="trace kernels compiled at run time for the scene's counts (rt_hip_ctx_set_jit; small scenes other "
+                         "than the reference's, for which the library has such kernels built in).  Default: now for such "
+                         "scenes (every context compiles before its first frame, so that the timed region runs one set of "
+                         "kernels), else auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-one-shot", action="store_true", help="skip the child processes that time the blocking raytrace() call")
     ap.add_argument("--no-generic", action="store_true", help="skip the short extra run with the generic kernels")
+    ap.add_argument("--no-small-scene", action="store_true", help="skip the short extra run on the 64-sphere scene")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -250,6 +295,8 @@ def main():
     if args.numerics is None:
         args.numerics = "fast" if builtin else "exact"
     scene = rt.Scene.builtin() if builtin else rt.Scene.synthetic(*scene_args)
+    if args.jit is None:
+        args.jit = "now" if (not builtin and scene_args[1] <= 128) else "auto"
     cam = rt.prepare_camera(scene, W, H, sqrt_spp, depth)
     plan = RowPlan(H, world)
     numerics = rt.NUMERICS_FAST if args.numerics == "fast" else rt.NUMERICS_EXACT
@@ -278,6 +325,8 @@ def main():
         c.set_numerics(numerics)
         c.set_launch_plan(args.launch_plan == "on")
         c.set_graph(args.graph == "on")
+        if args.jit != "auto":  # (auto: the library's policy - compile beside the frames after the eighth of a scene)
+            c.set_jit({"off": rt.JIT_OFF, "now": rt.JIT_NOW}[args.jit])
         if tail is not None:
             c.set_tail_stream(tail.cuda_stream)
         ctxs.append(c)
@@ -492,12 +541,32 @@ def main():
             out["roofline"]["one_frame_at_a_time"] = dict(
                 one_at_a_time(g), note="30 frames, each alone on the GPU, one stream: the kernel without a neighbour")
             if builtin:
-                # the same frames with the kernels any OTHER scene gets (nothing compiled for this scene's counts)
+                # the same frames with the kernels any OTHER scene gets: first the generic ones (counts are run-time
+                # values), which such a scene's first frames take, then the ones compiled at run time for the scene's
+                # counts (rt_jit.cpp), which its later frames take
                 g.set_specialization(False)
+                g.set_jit(rt.JIT_OFF)
                 out["generic_kernels"] = dict(
-                    one_at_a_time(g), note="30 frames, one at a time, with the kernels every scene shape other than the "
-                                           "reference's gets (rt_hip_ctx_set_specialization(ctx, 0))")
+                    one_at_a_time(g), note="30 frames, one at a time, with the library's kernels for any scene shape "
+                                           "(rt_hip_ctx_set_specialization(ctx, 0), rt_hip_ctx_set_jit(ctx, RT_JIT_OFF))")
+                g.set_jit(rt.JIT_NOW_ANY)
+                out["run_time_kernels"] = dict(
+                    one_at_a_time(g), note="30 frames, one at a time, with kernels compiled at run time for this scene's "
+                                           "counts as for any other small scene (rt_hip_ctx_set_jit(ctx, RT_JIT_NOW_ANY): "
+                                           "the library's own kernels for the reference's shape are not used)",
+                    compile_seconds=g.jit_status()[1])
+                g.set_jit(rt.JIT_AUTO)
                 g.set_specialization(True)
+            elif not grid_scene and args.jit != "off":
+                st_, sec_, _ = g.jit_status()
+                out["run_time_kernels"] = {"state": st_, "compile_seconds": sec_,
+                                           "note": "the timed region ran kernels compiled at run time for this scene's counts"}
+                g.set_jit(rt.JIT_OFF)
+                out["generic_kernels"] = dict(
+                    one_at_a_time(g), note="30 frames, one at a time, with the library's kernels for any scene shape")
+                g.set_jit(rt.JIT_NOW)
+            if builtin and cfg == "c2" and not args.no_small_scene:
+                out["small_scene"] = small_scene_line(dev, numerics, args.numerics)
         if world == 1 and builtin and not args.no_one_shot:
             # the call the reference's main() makes - raytrace() with the pixels in the caller's pageable buffer - timed in
             # child processes: a cold process from exec to exit, and the same process calling it frame after frame

@@ -352,6 +352,31 @@ int  rt_hip_ctx_set_pipeline(rt_hip_ctx *ctx, int mode);
  * No counterpart in the reference. */
 void rt_hip_ctx_set_specialization(rt_hip_ctx *ctx, int enable);
 
+/* Trace kernels compiled at run time for the uploaded scene's SHAPE.  The library holds the fused trace kernels for any
+ * scene (object and light counts are run-time values) and for the one shape the reference's parse_scene always
+ * returns (scene.c:86-258: every count a compile-time constant, a quarter faster).  For every other scene small
+ * enough for the fused kernels' LDS tables (up to RT_TILE_SPHERES spheres, tables within 20 KB) the context can have
+ * the same kernels compiled for that scene's counts (hiprtc, from the sources the library was built from, about a
+ * second per numerics build) - same expressions, same pixels; the exact build stays bit-identical.
+ *   RT_JIT_OFF      never
+ *   RT_JIT_AUTO     (default) once the context has submitted RT_JIT_AFTER frames of the scene, on a thread of its
+ *                   own: frames go on with the generic kernels and switch when the code is there; a failed compile
+ *                   changes nothing
+ *   RT_JIT_NOW      at the next render, which waits for the compile
+ *   RT_JIT_NOW_ANY  like RT_JIT_NOW, and also for the reference's shape instead of the library's kernels for it
+ *                   (measurement: what the run-time compile gives a scene the library has kernels for)
+ * The environment variable RT_HIP_JIT=<mode number> overrides every context.  Instrumented renders, the phong-blinn
+ * routine and big scenes take the library's kernels.  rt_hip_ctx_jit_status: 0 nothing asked for, 1 compiling,
+ * 2 ready, -1 failed, for the context's scene and numerics; the compiler's messages and the compile's duration on
+ * request.  No counterpart in the reference (its loops run over run-time counts, raytrace.c:188-272). */
+#define RT_JIT_OFF 0
+#define RT_JIT_AUTO 1
+#define RT_JIT_NOW 2
+#define RT_JIT_NOW_ANY 3
+#define RT_JIT_AFTER 8
+int rt_hip_ctx_set_jit(rt_hip_ctx *ctx, int mode);
+int rt_hip_ctx_jit_status(rt_hip_ctx *ctx, char *log, size_t log_bytes, double *compile_seconds);
+
 /* Launch plan of the fused primary kernel.  mode 0: the raster top-down, always.  mode 1 (the default): a render that
  * fits one image batch records how long every 8x8-pixel tile took; the next renders of the same frame shape on
  * this context launch the 32x8-pixel blocks slowest first, so that the kernel does not end on tiles that start

@@ -17,7 +17,7 @@ EXPORTS = [
     "rt_poly_plane", "rt_scene_builtin", "rt_parse_scene", "rt_scene_free", "rt_scene_synthetic",
     "rt_write_image", "write_image", "rt_hip_selftest_arith", "rt_load_scene", "rt_hip_deinterleave",
     "rt_hip_render_devices", "rt_hip_tone", "rt_hip_tone_sums", "rt_hip_tone_apply", "rt_hip_selftest_grid",
-    "rt_hip_tone_static", "rt_hip_ctx_set_numerics", "rt_hip_ctx_set_specialization", "rt_hip_ctx_set_launch_plan", "rt_hip_ctx_set_graph", "rt_launch_plan_order",
+    "rt_hip_tone_static", "rt_hip_ctx_set_numerics", "rt_hip_ctx_set_specialization", "rt_hip_ctx_set_jit", "rt_hip_ctx_jit_status", "rt_hip_ctx_set_launch_plan", "rt_hip_ctx_set_graph", "rt_launch_plan_order",
     "rt_hip_ctx_set_pipeline",
 ]
 
@@ -95,6 +95,10 @@ def load():
     lib.rt_hip_ctx_set_numerics.restype = i32
     lib.rt_hip_ctx_set_specialization.argtypes = [vp, i32]
     lib.rt_hip_ctx_set_specialization.restype = None
+    lib.rt_hip_ctx_set_jit.argtypes = [vp, i32]
+    lib.rt_hip_ctx_set_jit.restype = i32
+    lib.rt_hip_ctx_jit_status.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_double)]
+    lib.rt_hip_ctx_jit_status.restype = i32
     lib.rt_hip_ctx_set_launch_plan.argtypes = [vp, i32]
     lib.rt_hip_ctx_set_launch_plan.restype = None
     lib.rt_hip_ctx_set_graph.argtypes = [vp, i32]

@@ -120,6 +120,7 @@ def render(scene, cam, row0=0, nrows=None, want_radiance=True, devices=None):
 TONE_WARD, TONE_REINHARD = 1, 2
 SHADE_PHONG, SHADE_PHONGBLINN = 0, 1
 NUMERICS_EXACT, NUMERICS_FAST = 0, 1
+JIT_OFF, JIT_AUTO, JIT_NOW, JIT_NOW_ANY = 0, 1, 2, 3
 PIPELINE_AUTO, PIPELINE_FUSED = 0, 1
 
 
@@ -187,6 +188,17 @@ class Context:
         """PIPELINE_AUTO (big scenes through the job pipeline, csrc/rt_jobs.inc) or PIPELINE_FUSED (every scene through
         the fused primary / bounce kernels) - rt_hip_ctx_set_pipeline"""
         check(load().rt_hip_ctx_set_pipeline(self._h, int(mode)), "rt_hip_ctx_set_pipeline")
+
+    def set_jit(self, mode):
+        """JIT_OFF / JIT_AUTO / JIT_NOW / JIT_NOW_ANY: trace kernels compiled at run time for the scene's shape (rt_hip_ctx_set_jit)"""
+        check(load().rt_hip_ctx_set_jit(self._h, int(mode)), "rt_hip_ctx_set_jit")
+
+    def jit_status(self):
+        """(state, compile seconds, compiler log): 0 nothing asked for, 1 compiling, 2 ready, -1 failed"""
+        log = C.create_string_buffer(4096)
+        sec = C.c_double(0.0)
+        st = load().rt_hip_ctx_jit_status(self._h, log, len(log), C.byref(sec))
+        return st, sec.value, log.value.decode(errors="replace")
 
     def set_specialization(self, on):
         """False: generic kernels also for the reference's scene shape (rt_hip_ctx_set_specialization)"""

@@ -104,6 +104,11 @@ struct rt_hip_ctx {
     /* options */
     bool timing = false;
     bool no_shape = false; /* generic kernels only (survives scene uploads) */
+    /* kernels compiled at run time for the scene's shape (rt_jit.cpp, rt_hip_ctx_set_jit): the policy, the frames
+     * submitted since the scene (or the policy) changed, and what this frame launches (nullptr: the library's own) */
+    int jit_mode = RT_JIT_AUTO;
+    uint32_t jit_frames = 0;
+    const RtJitKernels *jit_cur = nullptr;
     bool no_jobs = false;  /* big scenes through the fused kernels too (rt_hip_ctx_set_pipeline) */
     int shading = RT_SHADE_PHONG;
     int numerics = RT_NUMERICS_EXACT;
@@ -408,9 +413,9 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
     if (R.plan)
         c->stats.planned_launches++;
     if (fast)
-        rt_launch_primary_fast(c->S, c->C, Wk, R, st);
+        rt_launch_primary_fast(c->S, c->C, Wk, R, st, c->jit_cur);
     else
-        rt_launch_primary(c->S, c->C, Wk, R, stats, c->shading == RT_SHADE_PHONGBLINN, st);
+        rt_launch_primary(c->S, c->C, Wk, R, stats, c->shading == RT_SHADE_PHONGBLINN, st, c->jit_cur);
     if (timed)
         HIP_TRY(hipEventRecord(c->ev.back(), st));
     const bool early = c->early_alias && !stats && c->d_argb && !c->job.interleaved;
@@ -453,13 +458,13 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
         const uint32_t expect = c->seen_valid ? (c->seen_hits[d] ? c->seen_hits[d] : 1u) : 0u;
         if (d == sub) {
             if (fast)
-                rt_launch_subtree_fast(c->S, c->C, Wk, d, expect, st);
+                rt_launch_subtree_fast(c->S, c->C, Wk, d, expect, st, c->jit_cur);
             else
-                rt_launch_subtree(c->S, c->C, Wk, d, expect, st);
+                rt_launch_subtree(c->S, c->C, Wk, d, expect, st, c->jit_cur);
         } else if (fast) {
-            rt_launch_bounce_fast(c->S, c->C, Wk, d, expect, st);
+            rt_launch_bounce_fast(c->S, c->C, Wk, d, expect, st, c->jit_cur);
         } else {
-            rt_launch_bounce(c->S, c->C, Wk, d, stats, expect, st);
+            rt_launch_bounce(c->S, c->C, Wk, d, stats, expect, st, c->jit_cur);
         }
     }
     if (cut && !moved) { /* (a cut below the last kernel launched: the folds and the resolve go to the tail) */
@@ -622,7 +627,7 @@ int enqueue_batch_graphed(rt_hip_ctx *c, const Batch &b, bool stats)
                              c->W.stride, c->W.cap, (uint64_t)(uintptr_t)c->pixAcc, (uint64_t)(uintptr_t)c->roots,
                              (uint64_t)(uintptr_t)c->tile_done, (uint64_t)(uintptr_t)c->d_counters,
                              (uint64_t)(uintptr_t)c->scene_blob, (uint64_t)(uintptr_t)(c->plan_use ? c->d_plan : nullptr),
-                             c->plan_use ? c->plan_len : 0u, (uint64_t)c->no_shape, (uint64_t)c->cwords,
+                             c->plan_use ? c->plan_len : 0u, (uint64_t)c->no_shape, (uint64_t)(uintptr_t)c->jit_cur, (uint64_t)c->cwords,
                              (uint64_t)c->stats.plan_builds};
     bytes(rest, sizeof rest);
     bytes(c->seen_hits, sizeof c->seen_hits);
@@ -1105,6 +1110,26 @@ void rt_hip_ctx_set_specialization(rt_hip_ctx *c, int enable)
         c->S.noShape = enable ? 0u : 1u;
         c->no_shape = !enable;
     }
+}
+
+int rt_hip_ctx_set_jit(rt_hip_ctx *c, int mode)
+{
+    if (!c || mode < RT_JIT_OFF || mode > RT_JIT_NOW_ANY) {
+        set_err("rt_hip_ctx_set_jit: mode %d", mode);
+        return RT_E_INVALID;
+    }
+    c->jit_mode = mode;
+    c->jit_frames = 0;
+    return 0;
+}
+
+int rt_hip_ctx_jit_status(rt_hip_ctx *c, char *log, size_t log_bytes, double *compile_seconds)
+{
+    if (!c || !c->have_scene) {
+        set_err("rt_hip_ctx_jit_status: no scene");
+        return RT_E_INVALID;
+    }
+    return rt_jit_status(c->S, c->numerics == RT_NUMERICS_FAST, log, log_bytes, compile_seconds);
 }
 
 int rt_hip_ctx_set_pipeline(rt_hip_ctx *c, int mode)
@@ -1788,6 +1813,7 @@ int rt_hip_scene_upload(rt_hip_ctx *c, const rt_scene *sc)
     if (!same) {
         c->seen_valid = false;
         c->scene_serial++;
+        c->jit_frames = 0;
     }
     return 0;
 }
@@ -1916,6 +1942,21 @@ static int submit(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb, float *
     rc = plan_frame(c, per >= job.ntiles && !jobs_path(c, job.stats));
     if (rc)
         return rc;
+    /* A small scene of another shape than the one the library has kernels for: after RT_JIT_AFTER frames of it the
+     * trace kernels are compiled for its counts, on a thread of their own, and the frames switch when they are there
+     * (RT_JIT_NOW: at once, and this frame waits). */
+    c->jit_cur = nullptr;
+    {
+        static const int env = [] { const char *e = getenv("RT_HIP_JIT"); return e ? atoi(e) : -1; }(); /* overrides every context's mode */
+        const int mode = env >= 0 ? env : c->jit_mode;
+        const bool any_shape = mode == RT_JIT_NOW_ANY;
+        if (mode != RT_JIT_OFF && !job.stats && c->shading == RT_SHADE_PHONG && !c->S.grid && c->S.tabInLds &&
+            (any_shape || (!c->no_shape && rt_scene_shape(c->S) == 0))) {
+            const bool now = mode >= RT_JIT_NOW;
+            c->jit_cur = rt_jit_get(c->S, c->numerics == RT_NUMERICS_FAST, now || c->jit_frames >= RT_JIT_AFTER, now);
+            c->jit_frames++;
+        }
+    }
     for (uint32_t t = job.ntiles; t > 0;) { /* pushed back to front: the list is popped from the end */
         const uint32_t n = (t % per) ? (t % per) : per;
         c->todo.push_back({t - n, t, 0});

@@ -33,8 +33,10 @@
  */
 #pragma once
 
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 #ifdef RT_FAST
 /*

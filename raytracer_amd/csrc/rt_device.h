@@ -6,8 +6,18 @@
  */
 #pragma once
 
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#else /* hiprtc (rt_jit.cpp): its built-in declarations, and the fixed-width names */
+typedef unsigned char uint8_t;
+typedef unsigned short uint16_t;
+typedef unsigned int uint32_t;
+typedef int int32_t;
+typedef unsigned long long uint64_t;
+typedef long long int64_t;
+typedef unsigned long uintptr_t;
+#endif
 
 #define RT_MAX_LEVELS   64          /* supported recursion depth: 0 .. RT_MAX_LEVELS-2 */
 #define RT_NONE         0xFFFFFFFFu
@@ -274,26 +284,29 @@ enum {
 };
 static_assert(2 * ST_COUNT <= CNT_STATS_STRIDE, "statistics do not fit their line");
 
-/* launch wrappers implemented in rt_kernels.hip (all asynchronous on `stream`) */
+#define RT_SUBTREE_LEVELS 8 /* k_subtree: at most this many levels below the one it takes its hits from */
+#ifndef __HIPCC_RTC__
+/* launch wrappers implemented in rt_kernels.hip (all asynchronous on `stream`).  `jit`: kernels compiled at run time for
+ * the scene's shape (rt_jit.cpp), or nullptr: the library's own */
+struct RtJitKernels;
 void rt_launch_fold_deep(const DevWork &Wk, uint32_t top_level, uint32_t bottom_level, hipStream_t stream);
 void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
-                       bool stats, bool blinn, hipStream_t stream);
+                       bool stats, bool blinn, hipStream_t stream, const RtJitKernels *jit = nullptr);
 /* the same two from the tolerance build of the kernels (rt_kernels.hip compiled with -DRT_FAST) */
 void rt_launch_primary_fast(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
-                            hipStream_t stream);
+                            hipStream_t stream, const RtJitKernels *jit = nullptr);
 void rt_launch_bounce_fast(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t level,
-                           uint32_t expect, hipStream_t stream);
+                           uint32_t expect, hipStream_t stream, const RtJitKernels *jit = nullptr);
 /* `expect` = entries per shard the launch is expected to find (0 = unknown: a full resident set).
  * It only sizes the grid; the kernels stride over whatever the counters say. */
 void rt_launch_bounce(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t level,
-                      bool stats, uint32_t expect, hipStream_t stream);
+                      bool stats, uint32_t expect, hipStream_t stream, const RtJitKernels *jit = nullptr);
 /* the hits queued for `level` and everything below them, depth first, in one launch (k_subtree): at most
  * RT_SUBTREE_LEVELS levels, i.e. depth - level < RT_SUBTREE_LEVELS */
-#define RT_SUBTREE_LEVELS 8
 void rt_launch_subtree(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t level,
-                       uint32_t expect, hipStream_t stream);
+                       uint32_t expect, hipStream_t stream, const RtJitKernels *jit = nullptr);
 void rt_launch_subtree_fast(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t level,
-                            uint32_t expect, hipStream_t stream);
+                            uint32_t expect, hipStream_t stream, const RtJitKernels *jit = nullptr);
 void rt_launch_fold(const DevWork &Wk, uint32_t level, uint32_t expect, hipStream_t stream);
 void rt_launch_resolve(const DevCamera &C, const DevWork &Wk, const DevRows &R, uint32_t *d_argb,
                        float *d_radiance, uint32_t *d_argb_host, hipStream_t stream);
@@ -323,3 +336,4 @@ void rt_launch_deinterleave(const uint32_t *gathered, uint32_t *frame, uint32_t 
                             uint32_t nphases, hipStream_t stream);
 void rt_launch_selftest_arith(const float *a, const float *b, const float *c, uint32_t n, float *out,
                               double *out64, hipStream_t stream);
+#endif /* !__HIPCC_RTC__ */

@@ -36,9 +36,12 @@
 #include "rt_arith.h"
 #include "rt_dev.h"
 
+#ifndef RT_JIT /* (RT_JIT: this file compiled at run time by hiprtc for one scene shape, rt_jit.cpp - device code only) */
 #include <math.h>
 #include <stdlib.h>
 #include <mutex>
+#include "rt_internal.h"
+#endif
 
 #ifndef RT_SPHERES_PER_TRIP
 #define RT_SPHERES_PER_TRIP 8u
@@ -769,6 +772,37 @@ __device__ __forceinline__ void intersect_all(const DevScene &S, const float4 *l
             }
         }
         if (!(BIG && ANYHIT && !STATS && found)) {
+            /* Four spheres per trip while four are left: their scalar loads (or LDS broadcasts) are in flight together
+             * and the tests of one trip share the loop's bookkeeping - with one sphere per trip a 64-sphere scene waited
+             * out a scalar-cache round trip per test (the tolerance build, half the arithmetic, was 9 % faster).
+             * Candidates are still taken in list order; an any-hit search may test up to three spheres more. */
+            constexpr uint32_t V = 4u;
+            for (; j + V <= cnt; j += V) {
+                float4 sq[V];
+                float Bq[V], detq[V];
+#pragma unroll
+                for (uint32_t u = 0; u < V; ++u)
+                    sq[u] = EYE ? eye_terms[j + u] : const_load4(S.sph + j + u);
+                bool any = false;
+#pragma unroll
+                for (uint32_t u = 0; u < V; ++u) {
+                    detq[u] = discriminant(sq[u], Bq[u]);
+                    if (FILTERED && (j + u) == exc_sph)
+                        detq[u] = -1.0f; /* the excluded sphere: never a candidate, never counted */
+                    else
+                        tl.sph_test();
+                    any = any || !(detq[u] < 0.0f);
+                }
+                if (any) {
+#pragma unroll
+                    for (uint32_t u = 0; u < V; ++u)
+                        if (!(detq[u] < 0.0f))
+                            candidate(j + u, Bq[u], detq[u], true);
+                }
+                if (ANYHIT && !STATS && __all(found)) /* (a wave-uniform exit: the loads of a trip are scalar) */
+                    break;
+            }
+            if (!(ANYHIT && !STATS && found))
             for (; j < cnt; ++j) {
                 /* (same address in all lanes: the eye terms as an LDS broadcast, the spheres themselves through
                  * the scalar cache - a wave-wide 16-byte LDS read occupies the CU's LDS pipeline for 8 cycles) */
@@ -1800,6 +1834,15 @@ template <> __device__ __forceinline__ void fix_shape<1>(DevScene &S)
 {
     S.nSph = 2u; S.nPoly = 1u; S.nPolySlots = 10u; S.nObj = 3u; S.nLights = 1u; S.tabSlots = 17u;
 }
+#ifdef RT_JIT
+/* SHAPE 2 = the shape this translation unit is being compiled for at run time (rt_jit.cpp: hiprtc at
+ * rt_hip_ctx_specialize, counts as macros): any scene of the small class gets what SHAPE 1 gives the reference's */
+template <> __device__ __forceinline__ void fix_shape<2>(DevScene &S)
+{
+    S.nSph = RT_JIT_NSPH; S.nPoly = RT_JIT_NPOLY; S.nPolySlots = RT_JIT_NPOLYSLOTS; S.nObj = RT_JIT_NOBJ;
+    S.nLights = RT_JIT_NLIGHTS; S.tabSlots = RT_JIT_TABSLOTS;
+}
+#endif
 
 /* a pixel's sum of sample colours -> the frame: x 1/spp^2 (raytrace.c:779), radiance, 8-bit pack (raytrace.c:783-790).
  * p: pixel of the batch.  k_resolve's last step, and k_primary's for the tiles without roots. */
@@ -1824,7 +1867,7 @@ __device__ __forceinline__ uint32_t store_pixel(const DevCamera &C, const DevRow
 /* k_primary: get_pixel_color + get_ray_color + depth-0 get_shade_color_phong, fused           */
 /* ------------------------------------------------------------------------------------------ */
 template <bool GRID, bool STATS, bool TABLDS, int SHAPE, bool BLINN = false>
-__global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 : RT_WPE)) void k_primary(DevScene S, DevCamera C, DevWork Wk,
+__global__ __launch_bounds__(RT_BLOCK, (SHAPE != 0 ? RT_WPE_SHAPE1 : TABLDS ? 6 : RT_WPE)) void k_primary(DevScene S, DevCamera C, DevWork Wk,
                                                       DevRows R)
 {
     fix_shape<SHAPE>(S);
@@ -1946,7 +1989,7 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
      * thirds of them - end without a global load waited for, an LDS word written or a barrier (a barrier
      * waits for the waves of its block that are still alive only).  What is left of the block then stages
      * wave by wave (Stagers). */
-    constexpr bool EARLY = SHAPE == 1 && !STATS;
+    constexpr bool EARLY = SHAPE != 0 && !STATS;
     if constexpr (EARLY) {
         if (classify_tile(ArgSource{S, C}))
             return;
@@ -2067,7 +2110,7 @@ __global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_SHAPE1 : TABLDS ? 6 
 /* k_bounce: one queued secondary ray per lane (reflection / transmission of level-1 nodes)    */
 /* ------------------------------------------------------------------------------------------ */
 template <bool GRID, bool STATS, bool TABLDS, int SHAPE>
-__global__ __launch_bounds__(RT_BLOCK, (SHAPE == 1 ? RT_WPE_BOUNCE1 : RT_WPE)) void k_bounce(DevScene S, DevCamera C, DevWork Wk,
+__global__ __launch_bounds__(RT_BLOCK, (SHAPE != 0 ? RT_WPE_BOUNCE1 : RT_WPE)) void k_bounce(DevScene S, DevCamera C, DevWork Wk,
                                                      uint32_t level)
 {
     fix_shape<SHAPE>(S);
@@ -2352,9 +2395,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_subtree(DevScene S, DevCamera C, D
     wave_add_total(st, ST_KB_TRANS, sc.trans);
 }
 
+#ifndef RT_JIT
 #include "rt_jobs.inc" /* the pipeline of big scenes: rays as jobs of persistent lanes */
+#endif
 
-#ifndef RT_FAST /* the kernels below do no arithmetic a tolerance could speed up: one copy, shared by both builds */
+#if !defined(RT_FAST) && !defined(RT_JIT) /* the kernels below do no arithmetic a tolerance could speed up: one copy, shared by both builds */
 /* colour of a tree node once both children are known: raytrace.c:440-442, 547-549, 562 */
 __device__ __forceinline__ uint32_t fold_values(const float4 A, const float2 K, const float4 cr,
                                                 const float4 ct, float out[3])
@@ -2599,11 +2644,20 @@ __global__ __launch_bounds__(RT_BLOCK) void k_selftest_grid(DevScene S, const fl
 #endif /* !RT_FAST */
 
 } // namespace RT_NSNAME
+#ifndef RT_JIT
 using namespace RT_NSNAME;
 
 /* ------------------------------------------------------------------------------------------ */
 /* launch wrappers                                                                            */
 /* ------------------------------------------------------------------------------------------ */
+
+/* a kernel compiled at run time for the scene's shape (rt_jit.cpp): the same arguments, through the module API */
+template <class A, class B, class C4, class D>
+static void launch_module(void *fn, dim3 grid, size_t lds, hipStream_t stream, const A &a, const B &b, const C4 &c, const D &d)
+{
+    void *args[] = {(void *)&a, (void *)&b, (void *)&c, (void *)&d};
+    (void)hipModuleLaunchKernel((hipFunction_t)fn, grid.x, grid.y, grid.z, RT_BLOCK, 1, 1, (unsigned int)lds, stream, args, nullptr);
+}
 
 #ifndef RT_FAST
 int rt_scene_shape(const DevScene &S)
@@ -2633,10 +2687,14 @@ size_t rt_scene_lds_bytes(const DevScene &S)
 /* the tolerance build's kernels: plain Phong renders only (the instrumented and phong-blinn variants
  * exist in the exact build alone; rt_api.hip routes those there) */
 void rt_launch_primary_fast(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
-                            hipStream_t stream)
+                            hipStream_t stream, const RtJitKernels *jit)
 {
     const dim3 grid((C.W + 31u) / 32u, R.ntiles);
     const size_t lds = rt_scene_lds_bytes(S);
+    if (jit) {
+        launch_module(jit->primary, R.plan ? dim3(R.plan_len) : grid, lds, stream, S, C, Wk, R);
+        return;
+    }
     const bool grid_scene = S.nSph > RT_TILE_SPHERES;
     void (*kernel)(DevScene, DevCamera, DevWork, DevRows) =
         grid_scene ? k_primary<true, false, false, 0>
@@ -2650,10 +2708,14 @@ void rt_launch_primary_fast(const DevScene &S, const DevCamera &C, const DevWork
 }
 #else
 void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
-                       bool stats, bool blinn, hipStream_t stream)
+                       bool stats, bool blinn, hipStream_t stream, const RtJitKernels *jit)
 {
     const dim3 grid((C.W + 31u) / 32u, R.ntiles);
     const size_t lds = rt_scene_lds_bytes(S);
+    if (jit && !stats && !blinn) {
+        launch_module(jit->primary, R.plan ? dim3(R.plan_len) : grid, lds, stream, S, C, Wk, R);
+        return;
+    }
     const bool grid_scene = S.nSph > RT_TILE_SPHERES;
     if (blinn) { /* get_shade_color_phongblinn (raytrace.c:574-685): the generic kernels only */
         void (*kernel)(DevScene, DevCamera, DevWork, DevRows) =
@@ -2689,7 +2751,7 @@ void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk,
  * rounded down to whole shards: a few blocks more and they would run as a second round after the
  * first has drained, doubling a latency-bound kernel (measured with 2048 blocks at 7 per CU).
  */
-static uint32_t queue_grid(const DevWork &Wk, const void *kernel, size_t lds, uint32_t expect)
+static uint32_t queue_grid(const DevWork &Wk, const void *kernel, size_t lds, uint32_t expect, bool module_fn = false)
 {
     struct Entry { const void *kernel; size_t lds; int device; uint32_t blocks; };
     constexpr int kCache = 256; /* devices x kernel variants x LDS sizes */
@@ -2705,7 +2767,9 @@ static uint32_t queue_grid(const DevWork &Wk, const void *kernel, size_t lds, ui
             resident = cache[i].blocks;
     if (!resident) {
         int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RT_BLOCK, lds) != hipSuccess || per_cu < 1)
+        const hipError_t rc = module_fn ? hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (hipFunction_t)kernel, RT_BLOCK, lds)
+                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RT_BLOCK, lds);
+        if (rc != hipSuccess || per_cu < 1)
             per_cu = 4;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1)
             cus = 256;
@@ -2729,9 +2793,13 @@ static uint32_t queue_grid(const DevWork &Wk, const void *kernel, size_t lds, ui
 
 #ifdef RT_FAST
 void rt_launch_bounce_fast(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t level,
-                           uint32_t expect, hipStream_t stream)
+                           uint32_t expect, hipStream_t stream, const RtJitKernels *jit)
 {
     const size_t lds = rt_scene_lds_bytes(S);
+    if (jit) {
+        launch_module(jit->bounce, dim3(queue_grid(Wk, jit->bounce, lds, expect, true)), lds, stream, S, C, Wk, level);
+        return;
+    }
     const bool grid_scene = S.nSph > RT_TILE_SPHERES;
     void (*kernel)(DevScene, DevCamera, DevWork, uint32_t) =
         grid_scene ? k_bounce<true, false, false, 0>
@@ -2741,9 +2809,13 @@ void rt_launch_bounce_fast(const DevScene &S, const DevCamera &C, const DevWork 
     kernel<<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, level);
 }
 void rt_launch_subtree_fast(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t level,
-                            uint32_t expect, hipStream_t stream)
+                            uint32_t expect, hipStream_t stream, const RtJitKernels *jit)
 {
     const size_t lds = rt_scene_lds_bytes(S);
+    if (jit) {
+        launch_module(jit->subtree, dim3(queue_grid(Wk, jit->subtree, lds, expect, true)), lds, stream, S, C, Wk, level);
+        return;
+    }
     const bool grid_scene = S.nSph > RT_TILE_SPHERES;
     void (*kernel)(DevScene, DevCamera, DevWork, uint32_t) =
         grid_scene ? k_subtree<true, false, 0>
@@ -2754,9 +2826,13 @@ void rt_launch_subtree_fast(const DevScene &S, const DevCamera &C, const DevWork
 }
 #else
 void rt_launch_bounce(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t level,
-                      bool stats, uint32_t expect, hipStream_t stream)
+                      bool stats, uint32_t expect, hipStream_t stream, const RtJitKernels *jit)
 {
     const size_t lds = rt_scene_lds_bytes(S);
+    if (jit && !stats) {
+        launch_module(jit->bounce, dim3(queue_grid(Wk, jit->bounce, lds, expect, true)), lds, stream, S, C, Wk, level);
+        return;
+    }
     const bool grid_scene = S.nSph > RT_TILE_SPHERES;
     void (*kernel)(DevScene, DevCamera, DevWork, uint32_t) =
         grid_scene ? (stats ? k_bounce<true, true, false, 0> : k_bounce<true, false, false, 0>)
@@ -2768,9 +2844,13 @@ void rt_launch_bounce(const DevScene &S, const DevCamera &C, const DevWork &Wk, 
 }
 
 void rt_launch_subtree(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t level,
-                       uint32_t expect, hipStream_t stream)
+                       uint32_t expect, hipStream_t stream, const RtJitKernels *jit)
 {
     const size_t lds = rt_scene_lds_bytes(S);
+    if (jit) {
+        launch_module(jit->subtree, dim3(queue_grid(Wk, jit->subtree, lds, expect, true)), lds, stream, S, C, Wk, level);
+        return;
+    }
     const bool grid_scene = S.nSph > RT_TILE_SPHERES;
     void (*kernel)(DevScene, DevCamera, DevWork, uint32_t) =
         grid_scene ? k_subtree<true, false, 0>
@@ -2902,3 +2982,4 @@ extern "C" int rt_dev_tile_trace_read(void *host, size_t bytes)
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(rt_tile_trace), bytes);
 }
 #endif
+#endif /* !RT_JIT */
