@@ -577,25 +577,26 @@ def test_c4_sparse_pins_at_full_size(torch_cuda, golden, make_scene, name, W, H,
     cam = rt.prepare_camera(sc, W, H, s, d)
     ctx = rt.Context(queue_cap=1 << 22)
     ctx.upload(sc)
-    xy, want = arrays[sp["key"] + "_xy"][:16], arrays[sp["key"] + "_rad"][:16]
+    xy, want = arrays[sp["key"] + "_xy"], arrays[sp["key"] + "_rad"]  # every pin the fixture holds (48)
     ok = 0
     for (x, y), w in zip(xy, want):
         _, rad, _ = render_dev(torch_cuda, ctx, cam, int(y), 1)
         rel = np.abs(rad[y, x] - w) / np.maximum(np.abs(w), 1e-3)
         ok += bool((rel <= 1e-4).all())
-    assert ok == 16
+    assert ok == len(xy) >= 48
     ctx.close()
 
 
 def test_c5_sparse_pins_tiled_scene(torch_cuda, golden, make_scene):
-    """BASELINE config 5 (16 384 spheres in 8 LDS tiles, 8 lights, depth 16, 8K, 64 spp)."""
+    """BASELINE config 5 (16 384 spheres searched through the grid in HBM, 8 lights, depth 16, 8K, 64 spp)."""
     meta, arrays = golden
     sp = meta["sparse"][4]
     sc = make_scene("c5")
     cam = rt.prepare_camera(sc, 7680, 4320, 8, 16)
     ctx = rt.Context(queue_cap=1 << 24)  # a tile row of this frame is 3.9 M samples, and the job pipeline logs ~2 hits per sample
     ctx.upload(sc)
-    xy, want = arrays[sp["key"] + "_xy"][:4], arrays[sp["key"] + "_rad"][:4]
+    xy, want = arrays[sp["key"] + "_xy"], arrays[sp["key"] + "_rad"]  # every pin the fixture holds (12)
+    assert len(xy) >= 12
     for (x, y), w in zip(xy, want):
         _, rad, _ = render_dev(torch_cuda, ctx, cam, int(y), 1)
         rel = np.abs(rad[y, x] - w) / np.maximum(np.abs(w), 1e-3)
@@ -1132,7 +1133,7 @@ def test_c3_full_frame_hash_and_counts(torch_cuda, make_scene):
 
 @pytest.mark.parametrize("name", ["c4", "c5"])
 def test_big_scene_frames_against_the_reference(torch_cuda, make_scene, name):
-    """The scenes of configs 4 (1024 spheres + 4 quads: spheres in LDS tiles) and 5 (16 384 spheres, 8 lights,
+    """The scenes of configs 4 (1024 spheres + 4 quads: spheres searched through the grid in HBM) and 5 (16 384 spheres, 8 lights,
     depth 16: the sphere grid) as whole frames at a reduced size, against frames the reference rendered:
     identical 8-bit pictures, radiance within 1e-4 on every pixel, ray counts equal to its counters."""
     meta, arrays = _frames_fixture()

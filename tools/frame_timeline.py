@@ -1,11 +1,16 @@
 import re
 #!/usr/bin/env python3
-"""Per-kernel timeline of the last full frame in a rocprofv3 --kernel-trace directory."""
+"""Per-kernel timeline of a frame that had the GPU to itself in a rocprofv3 --kernel-trace directory of bench.py: the
+last frame but one of the kernels compiled into the library for the reference's scene shape (the one-frame-at-a-time
+section of the bench; any frame if there is no such kernel in the trace)."""
 import csv, glob, sys
 d = sys.argv[1]
-rows = list(csv.DictReader(open(glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0])))
+import os
+rows = list(csv.DictReader(open(max(glob.glob(d + "/**/*kernel_trace.csv", recursive=True), key=os.path.getsize))))
 ks = sorted((r for r in rows if "k_" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(ks) if "k_primary<" in r["Kernel_Name"] and not re.search(r"k_primary<\w+, true,", r["Kernel_Name"])]
+own = [i for i in idx if re.search(r"k_primary<\w+, \w+, \w+, 1", ks[i]["Kernel_Name"])]
+idx = own if len(own) >= 2 else idx
 s, e = idx[-2], idx[-1]
 t0 = int(ks[s]["Start_Timestamp"])
 for r in ks[s:e]:
