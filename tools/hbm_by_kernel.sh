@@ -17,7 +17,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     ids = ids[len(ids) * 2 // 3:]  # the last third of the run: planned, sized frames
     for i in ids:
         m = re.search(r"(k_[a-z_]+)(<[^>]*>)?", name[i]); k = m.group(1) if m else name[i][:20]
-        if k == "k_bounce" or k == "k_fold": k += " grid " + grid[i]
+        if k in ("k_bounce", "k_fold", "k_primary"): k += " grid " + grid[i]  # (k_primary: whole frames and the batches of a context's sizing frames)
         tot[k][ctr].append(per[i])
 for k, v in sorted(tot.items()):
     f = sum(v["FETCH_SIZE"]) / max(len(v["FETCH_SIZE"]), 1); w = sum(v["WRITE_SIZE"]) / max(len(v["WRITE_SIZE"]), 1)

@@ -31,8 +31,11 @@ for num in ("fast", "exact"):
             grid[(name, r["Dispatch_Id"])] = int(r["Grid_Size"])
         # k_primary: whole frames only (a context's first frames size its queues and are rendered in batches)
         full = max((g for (n, _), g in grid.items() if "k_primary" in n), default=0)
+        # ... and of those the last third of the run: sized, planned frames (what tools/hbm_by_kernel.sh takes as well)
+        ids = sorted({int(dsp) for (n, dsp), g in grid.items() if "k_primary" in n and g == full})
+        keep = set(ids[len(ids) * 2 // 3:])
         for (name, disp, ctr), v in per.items():
-            if "k_primary" in name and grid[(name, disp)] != full:
+            if "k_primary" in name and int(disp) not in keep:
                 continue
             agg[name][ctr].append(v)
     build = {}
