@@ -277,9 +277,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1 and not fake:
+    # RT_BENCH_RCCL_WORLD1=1 (one GPU): the path of many ranks with a world of ONE - process group, barriers, the in-place
+    # all-gather, the de-interleave, the all-reduces: every RCCL call of an N-GPU run executes, on the hardware there is
+    rccl1 = world == 1 and not fake and bool(os.environ.get("RT_BENCH_RCCL_WORLD1"))
+    if (world > 1 and not fake) or rccl1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = args.config or ("c2" if world == 1 else "c3")
@@ -332,7 +336,7 @@ def main():
         ctxs.append(c)
 
     def render(i, k, target, stream):
-        if world == 1:
+        if world == 1 and not rccl1:
             ctxs[k].render_rows(cam, target.data_ptr(), 0, 0, H, stream.cuda_stream)
         else:
             ctxs[k].render_interleaved(cam, target.data_ptr(), 0, rank, world, stream.cuda_stream)
@@ -343,7 +347,7 @@ def main():
     pipe = FramePipeline(plan, W, torch.int32, dev, rank, render, finish, inflight=inflight,  # 0xFFRRGGBB bit patterns
                          gather_stream=args.gather_stream, done_stream=tail, collective=not fake,
                          render_streams=[torch.cuda.Stream(device=dev) for _ in range(inflight)] if args.overlap else None,
-                         render_priority=args.render_priority)
+                         render_priority=args.render_priority, force_collective=rccl1)
 
     # instrumented pass (outside the timed region, exact kernels): algorithmic work of this rank's share
     full = torch.zeros((H, W), dtype=torch.int32, device=dev)
@@ -454,7 +458,8 @@ def main():
             "dtype": "f32",
             "data": ("synthetic (the reference's hard-coded Whitted scene, scene.c:86-258)" if builtin else
                      "synthetic (seeded random scene, rt_scene_synthetic)")
-                    + (f"; REHEARSAL of rank {rank} of {world} on one GPU, no collective" if fake else ""),
+                    + (f"; REHEARSAL of rank {rank} of {world} on one GPU, no collective" if fake else "")
+                    + ("; REHEARSAL of the multi-rank path with a world of one: every RCCL call runs" if rccl1 else ""),
             "config": {"workload": f"{cfg}: {scene_name} {W}x{H}, sqrtSpp {sqrt_spp} ({sqrt_spp * sqrt_spp} spp), "
                                    f"depth {depth}{split}",
                        "rays_per_step": rays_all / steps,

@@ -61,8 +61,9 @@ def deinterleave(gathered, plan, out=None):
 class FrameGather:
     """Pre-allocated buffers for `all-gather the local slices, de-interleave into the frame`."""
 
-    def __init__(self, plan, width, dtype, device, trailing=(), rank=0):
+    def __init__(self, plan, width, dtype, device, trailing=(), rank=0, force=False):
         self.plan = plan
+        self.force = force  # a world of one goes through the collective too (rehearsal of the multi-rank path on one GPU)
         self.width = width
         shape_tail = (width,) + tuple(trailing)
         self.gathered = torch.zeros((plan.world * plan.local_rows,) + shape_tail, dtype=dtype, device=device)
@@ -81,7 +82,7 @@ class FrameGather:
 
     def gather(self, group=None, collective=True, stream=None):
         """all-gather (on the current stream) + de-interleave (on `stream`, default the current one)"""
-        if self.plan.world > 1 and collective:
+        if (self.plan.world > 1 or self.force) and collective:
             import torch.distributed as dist
             dist.all_gather_into_tensor(self._flat[0], self._flat[1], group=group)
         return self.rebuild(stream)
@@ -142,21 +143,24 @@ class FramePipeline:
 
     def __init__(self, plan, width, dtype, device, rank, render, finish, inflight=2, gather_stream="side",
                  done_stream=None, collective=True, group=None, render_streams=None, trailing=(),
-                 render_priority="normal"):
+                 render_priority="normal", force_collective=False):
         self.plan, self.rank, self.inflight = plan, rank, max(1, inflight)
         self.render_fn, self.finish_fn = render, finish
         self.collective, self.group = collective, group
+        # force_collective: one rank takes the path of many - local slice, all-gather (of one), de-interleave: every
+        # RCCL call of the multi-rank path runs, on the one GPU there is (bench.py RT_BENCH_RCCL_WORLD1, tests)
+        self.multi = plan.world > 1 or force_collective
         self.cuda = torch.device(device).type == "cuda"
-        self.gathers = [FrameGather(plan, width, dtype, device, trailing=trailing, rank=rank) for _ in range(self.inflight)]
+        self.gathers = [FrameGather(plan, width, dtype, device, trailing=trailing, rank=rank, force=force_collective) for _ in range(self.inflight)]
         if self.cuda:
             shared = torch.cuda.Stream(device=device, priority=-1 if render_priority == "high" else 0)
             self.streams = list(render_streams) if render_streams else [shared] * self.inflight
-            self.comm = (torch.cuda.Stream(device=device) if gather_stream == "side" else None) if plan.world > 1 else None
+            self.comm = (torch.cuda.Stream(device=device) if gather_stream == "side" else None) if self.multi else None
             self.rendered = [torch.cuda.Event() for _ in range(self.inflight)]
             self.gathered = [torch.cuda.Event() for _ in range(self.inflight)]
         else:
             self.streams = [_NoStream()] * self.inflight
-            self.comm = _NoStream() if plan.world > 1 and gather_stream == "side" else None
+            self.comm = _NoStream() if self.multi and gather_stream == "side" else None
             self.rendered = [_NoStream() for _ in range(self.inflight)]
             self.gathered = [_NoStream() for _ in range(self.inflight)]
         self.done_stream = done_stream  # where a frame is complete when it is not its render stream
@@ -169,7 +173,7 @@ class FramePipeline:
         st, fg = self.streams[k], self.gathers[k]
         # (render_fn is handed its stream; no stream context around it: entering and leaving one costs the host
         # 10 us a frame, and with more than one rank the host is what bounds the frame rate)
-        if self.plan.world == 1:
+        if not self.multi:
             self.render_fn(i, k, fg.frame, st)  # one rank: straight into the frame, nothing to gather
             return
         if i >= self.inflight:
@@ -191,7 +195,7 @@ class FramePipeline:
         is not looked at, and the retries are no error"""
         k = i % self.inflight
         stats = self.finish_fn(i, k)
-        if self.plan.world > 1 and not sizing and stats is not None and getattr(stats, "overflow_retries", 0):
+        if self.multi and not sizing and stats is not None and getattr(stats, "overflow_retries", 0):
             raise RuntimeError("a batch of frame %d overflowed its queues and was rendered again after its rows had "
                                "been gathered: raise the context's capacity" % i)
         return stats
