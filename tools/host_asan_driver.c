@@ -65,9 +65,17 @@ int main(void)
         hipStreamCreateWithFlags(&main_s, hipStreamNonBlocking) || hipStreamCreateWithFlags(&tail_s, hipStreamNonBlocking))
         return 1;
     rt_hip_stats st;
-    for (int pass = 0; pass < 4; ++pass) {
+    for (int pass = 0; pass < 5; ++pass) {
+        CHECK(rt_hip_ctx_set_jit(ctx, pass == 4 ? RT_JIT_NOW : RT_JIT_OFF)); /* (pass 4: kernels compiled for this scene's counts) */
         CHECK(rt_hip_ctx_set_tail_stream(ctx, pass >= 2 ? tail_s : NULL));
         CHECK(rt_hip_ctx_set_shading(ctx, pass == 3 ? RT_SHADE_PHONGBLINN : RT_SHADE_PHONG));
+        if (pass == 4) {
+            char log[256];
+            double sec = 0.0;
+            CHECK(rt_hip_render_rows(ctx, &cam, d_argb, d_rad, 0, 120, main_s));
+            CHECK(rt_hip_finish(ctx, &st));
+            printf("jit status %d (%.2f s)\n", rt_hip_ctx_jit_status(ctx, log, sizeof log, &sec), sec);
+        }
         CHECK(rt_hip_render_rows(ctx, &cam, d_argb, d_rad, 0, 120, main_s));
         CHECK(rt_hip_finish(ctx, &st));
         printf("pass %d: batches %u retries %u nodes %llu\n", pass, st.batches, st.overflow_retries,
