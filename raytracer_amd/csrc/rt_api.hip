@@ -1432,25 +1432,28 @@ void build_grid(const std::vector<float4> &sph, const rt_scene *sc, const std::v
         if (pass == 1) {
             /* ... and the cells once more as 64-byte chunks with their spheres inline (CellChunk) */
             const size_t lists = G.words + cells + 1 + items.size();
-            const bool chunked = n <= RT_CHUNK_MAX_SPHERES;
+            const bool chunked = n <= RT_CHUNK_MAX_SPHERES && sc->nObjects <= RT_CHUNK_MAX_SPHERES;
             G.rec_words = chunked ? (uint32_t)((lists + 15u) & ~(size_t)15u) : 0u;
             G.pad_[0] = G.pad_[1] = G.pad_[2] = 0u;
             std::vector<CellChunk> chunks;
             if (chunked) {
                 chunks.assign(cells, CellChunk{});
                 auto fill_chunk = [&](CellChunk &ck, uint32_t beg, uint32_t cnt) { /* up to three of the items from beg on */
-                    uint32_t k[RT_CHUNK_SPHERES] = {0u, 0u, 0u};
+                    uint32_t k[RT_CHUNK_SPHERES] = {0u, 0u, 0u}; /* OBJECT indices (ascending with the sphere index) */
                     for (uint32_t u = 0; u < cnt && u < RT_CHUNK_SPHERES; ++u) {
-                        k[u] = items[beg + u];
-                        ck.sph[u] = sph[k[u]];
+                        const uint32_t ks = items[beg + u];
+                        k[u] = sph_obj[ks];
+                        ck.sph[u] = sph[ks];
+                        const rt_material &m = sc->objects[k[u]].material; /* raytrace.c:405,452: what a hit on it spawns */
+                        ck.count |= ((m.kr != 0.0f ? 1u : 0u) | (m.kt != 0.0f ? 2u : 0u)) << (24u + 2u * u);
                     }
                     ck.idx_lo = k[0] | (k[1] << 21);
                     ck.idx_hi = (k[1] >> 11) | (k[2] << 10);
                 };
                 for (size_t ci = 0; ci < cells; ++ci) {
                     const uint32_t beg = count[ci], cnt = count[ci + 1] - beg;
-                    chunks[ci].count = cnt;
                     fill_chunk(chunks[ci], beg, cnt);
+                    chunks[ci].count |= cnt; /* (< 2^24: RT_CHUNK_MAX_SPHERES) */
                     if (cnt > RT_CHUNK_SPHERES) {
                         chunks[ci].next = (uint32_t)chunks.size();
                         for (uint32_t u = RT_CHUNK_SPHERES; u < cnt; u += RT_CHUNK_SPHERES) {

@@ -103,11 +103,18 @@ struct GridHeader {
  * in a 128-byte record - every iteration ran six test blocks for the one lane in a fuller cell (config 4: 2.2
  * spheres per occupied cell, 13 % of them hold more than three), and a walking lane's eight 16-byte loads each cost
  * the CU's vector memory pipe a cache-line look-up per lane.
- *   chunk c < cells: the first chunk of cell c: count = the cell's spheres, the first three inline; if count > 3 the
- *   others follow from chunk `next` on, three to a chunk, one behind the other (their count and next are 0).
- *   Sphere indices: 21 bits each (RT_CHUNK_MAX_SPHERES), i0 | i1 << 21 in idx_lo, i1 >> 11 | i2 << 10 in idx_hi. */
+ *   chunk c < cells: the first chunk of cell c: count (low 24 bits) = the cell's spheres, the first three inline; if
+ *   count > 3 the others follow from chunk `next` on, three to a chunk, one behind the other (count and next 0 there).
+ *   Per sphere: its OBJECT index, 21 bits (RT_CHUNK_MAX_SPHERES; object indices ascend with sphere indices, so "the
+ *   lower index wins a tie" reads the same on either), i0 | i1 << 21 in idx_lo, i1 >> 11 | i2 << 10 in idx_hi, and in
+ *   bits 24 + 2u, 25 + 2u of `count` whether a hit on sphere u spawns a reflection / a transmission ray (material
+ *   kr != 0, kt != 0: raytrace.c:405,452) - a hit is queued as object | flags << 30 (RT_HIT_*), so that the next
+ *   level knows which rays a hit asks for without looking its material up. */
 #define RT_CHUNK_SPHERES 3u
 #define RT_CHUNK_MAX_SPHERES (1u << 21)
+#define RT_HIT_OBJ 0x3FFFFFFFu  /* a queued hit of the job pipeline: the object ... */
+#define RT_HIT_REFL 0x40000000u /* ... spawns a reflection ray */
+#define RT_HIT_TRANS 0x80000000u /* ... spawns a transmission ray */
 struct CellChunk {
     uint32_t count;
     uint32_t idx_lo, idx_hi;
