@@ -28,7 +28,7 @@ FLOP constants of SURVEY.md section 8d against the FP32 vector peak: reference-e
 utilisation - `roofline.executed_frac` (vector lane operations really issued / what the SIMDs can issue) is
 that.  `cpu_baseline` times the reference (or the oracle port) on the host.
 
-Three frames are in flight (a render context each), on ONE render stream of high priority - k_primary and the wide
+Three frames are in flight (a render context each), on ONE render stream - k_primary and the wide
 bounce levels, back to back - and ONE tail stream for every frame's sparse deep end (k_subtree), folds, resolve
 and publish, which drain beside the next frame's kernels.  `roofline` times k_primary inside that timed region;
 `roofline.one_frame_at_a_time` is the same kernel with each frame alone on the GPU.
@@ -216,10 +216,12 @@ def main():
                     help="frames submitted ahead (each with its own render context) on ONE render stream plus ONE tail "
                          "stream: three keep the host two frames ahead of the GPU, so that the next k_primary is queued "
                          "when the render stream falls free (two: 0.228 ms per frame, three: 0.225, four: 0.220)")
-    ap.add_argument("--render-priority", choices=["high", "normal"], default="high",
+    ap.add_argument("--render-priority", choices=["high", "normal"], default="normal",
                     help="HIP stream priority of the shared render stream (k_primary and the wide bounce levels); the tail "
-                         "stream has the normal one.  high: the tail of frame i fills what k_primary of frame i+1 leaves "
-                         "(0.225 ms per frame, k_primary 0.114 ms with three frames in flight); normal: the two share alike (0.212 ms, 0.124 ms)")
+                         "stream has the normal one.  normal (round 3: 0.183 ms per frame, k_primary 0.1095 ms in the pipeline): the "
+                         "two share alike; high (0.190 ms, 0.1085 ms): the tail of frame i only fills what k_primary of frame i+1 "
+                         "leaves - its kernels then take 2.5 times as long as alone and the tail stream, not the render stream, "
+                         "sets the period (round 2, with a heavier tail: high 0.190, normal 0.194)")
     ap.add_argument("--launch-plan", choices=["on", "off"], default="on",
                     help="k_primary's launch plan (rt_hip_ctx_set_launch_plan): each context times the tiles of its first "
                          "frame and launches the blocks of the next ones slowest first; off: raster order, top-down "
