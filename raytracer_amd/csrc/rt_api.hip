@@ -370,7 +370,8 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
         HIP_TRY(hipEventCreate(&e1));
         c->ev.push_back(e0);
         c->ev.push_back(e1);
-        HIP_TRY(hipEventRecord(e0, st));
+        if (jobs_path(c, stats)) /* (several kernels: bracketed; the fused k_primary takes the events itself) */
+            HIP_TRY(hipEventRecord(e0, st));
     }
     /* the tolerance build has the plain Phong kernels only: instrumented and phong-blinn renders run the exact ones */
     const bool fast = c->numerics == RT_NUMERICS_FAST && !stats && c->shading == RT_SHADE_PHONG;
@@ -412,12 +413,12 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
     }
     if (R.plan)
         c->stats.planned_launches++;
+    /* timed: the kernel's own start and end (hipExtLaunchKernel), not two events around its dispatch */
+    hipEvent_t t0 = timed ? c->ev[c->ev.size() - 2] : nullptr, t1 = timed ? c->ev.back() : nullptr;
     if (fast)
-        rt_launch_primary_fast(c->S, c->C, Wk, R, st, c->jit_cur);
+        rt_launch_primary_fast(c->S, c->C, Wk, R, st, c->jit_cur, t0, t1);
     else
-        rt_launch_primary(c->S, c->C, Wk, R, stats, c->shading == RT_SHADE_PHONGBLINN, st, c->jit_cur);
-    if (timed)
-        HIP_TRY(hipEventRecord(c->ev.back(), st));
+        rt_launch_primary(c->S, c->C, Wk, R, stats, c->shading == RT_SHADE_PHONGBLINN, st, c->jit_cur, t0, t1);
     const bool early = c->early_alias && !stats && c->d_argb && !c->job.interleaved;
     const size_t early_off = (size_t)R.out_first * c->C.W;
     const uint32_t early_rows = (!c->job.interleaved && R.y_first + R.ntiles * 8u > R.y_limit) ? R.y_limit - R.y_first : R.ntiles * 8u;

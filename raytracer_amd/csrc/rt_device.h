@@ -297,11 +297,14 @@ static_assert(2 * ST_COUNT <= CNT_STATS_STRIDE, "statistics do not fit their lin
  * the scene's shape (rt_jit.cpp), or nullptr: the library's own */
 struct RtJitKernels;
 void rt_launch_fold_deep(const DevWork &Wk, uint32_t top_level, uint32_t bottom_level, hipStream_t stream);
+/* ev0 / ev1 (both or neither): events that take the kernel's own start and end (hipExtLaunchKernel) */
 void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
-                       bool stats, bool blinn, hipStream_t stream, const RtJitKernels *jit = nullptr);
+                       bool stats, bool blinn, hipStream_t stream, const RtJitKernels *jit = nullptr,
+                       hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 /* the same two from the tolerance build of the kernels (rt_kernels.hip compiled with -DRT_FAST) */
 void rt_launch_primary_fast(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
-                            hipStream_t stream, const RtJitKernels *jit = nullptr);
+                            hipStream_t stream, const RtJitKernels *jit = nullptr, hipEvent_t ev0 = nullptr,
+                            hipEvent_t ev1 = nullptr);
 void rt_launch_bounce_fast(const DevScene &S, const DevCamera &C, const DevWork &Wk, uint32_t level,
                            uint32_t expect, hipStream_t stream, const RtJitKernels *jit = nullptr);
 /* `expect` = entries per shard the launch is expected to find (0 = unknown: a full resident set).

@@ -40,6 +40,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <mutex>
+#include <hip/hip_ext.h>
 #include "rt_internal.h"
 #endif
 
@@ -2653,10 +2654,24 @@ using namespace RT_NSNAME;
 
 /* a kernel compiled at run time for the scene's shape (rt_jit.cpp): the same arguments, through the module API */
 template <class A, class B, class C4, class D>
-static void launch_module(void *fn, dim3 grid, size_t lds, hipStream_t stream, const A &a, const B &b, const C4 &c, const D &d)
+static void launch_module(void *fn, dim3 grid, size_t lds, hipStream_t stream, const A &a, const B &b, const C4 &c, const D &d,
+                          hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
 {
     void *args[] = {(void *)&a, (void *)&b, (void *)&c, (void *)&d};
-    (void)hipModuleLaunchKernel((hipFunction_t)fn, grid.x, grid.y, grid.z, RT_BLOCK, 1, 1, (unsigned int)lds, stream, args, nullptr);
+    if (ev0) /* (the "ext" launch counts threads, not blocks) */
+        (void)hipExtModuleLaunchKernel((hipFunction_t)fn, grid.x * RT_BLOCK, grid.y, grid.z, RT_BLOCK, 1, 1, lds, stream, args, nullptr, ev0, ev1, 0);
+    else
+        (void)hipModuleLaunchKernel((hipFunction_t)fn, grid.x, grid.y, grid.z, RT_BLOCK, 1, 1, (unsigned int)lds, stream, args, nullptr);
+}
+/* a kernel of the library, with events that take its own start and end when the caller times it: two events recorded
+ * around the launch bracket the dispatch packet and read 6-9 us long beside a busy tail stream */
+static void launch_primary(void (*kernel)(DevScene, DevCamera, DevWork, DevRows), dim3 grid, size_t lds, hipStream_t stream,
+                           const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R, hipEvent_t ev0, hipEvent_t ev1)
+{
+    if (ev0)
+        hipExtLaunchKernelGGL(kernel, grid, dim3(RT_BLOCK), (unsigned int)lds, stream, ev0, ev1, 0, S, C, Wk, R);
+    else
+        kernel<<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, R);
 }
 
 #ifndef RT_FAST
@@ -2687,12 +2702,12 @@ size_t rt_scene_lds_bytes(const DevScene &S)
 /* the tolerance build's kernels: plain Phong renders only (the instrumented and phong-blinn variants
  * exist in the exact build alone; rt_api.hip routes those there) */
 void rt_launch_primary_fast(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
-                            hipStream_t stream, const RtJitKernels *jit)
+                            hipStream_t stream, const RtJitKernels *jit, hipEvent_t ev0, hipEvent_t ev1)
 {
     const dim3 grid((C.W + 31u) / 32u, R.ntiles);
     const size_t lds = rt_scene_lds_bytes(S);
     if (jit) {
-        launch_module(jit->primary, R.plan ? dim3(R.plan_len) : grid, lds, stream, S, C, Wk, R);
+        launch_module(jit->primary, R.plan ? dim3(R.plan_len) : grid, lds, stream, S, C, Wk, R, ev0, ev1);
         return;
     }
     const bool grid_scene = S.nSph > RT_TILE_SPHERES;
@@ -2701,19 +2716,17 @@ void rt_launch_primary_fast(const DevScene &S, const DevCamera &C, const DevWork
         : rt_scene_shape(S) == 1 ? k_primary<false, false, true, 1>
         : S.tabInLds ? k_primary<false, false, true, 0> : k_primary<false, false, false, 0>;
     static const size_t pad_to = [] { const char *e = getenv("RT_HIP_PRIMARY_LDS"); return e ? (size_t)atol(e) : 0; }(); /* as in rt_launch_primary */
-    if (R.plan) /* (a plan is a list of blocks) */
-        kernel<<<R.plan_len, RT_BLOCK, lds < pad_to && pad_to <= 65536 ? pad_to : lds, stream>>>(S, C, Wk, R);
-    else
-        kernel<<<grid, RT_BLOCK, lds < pad_to && pad_to <= 65536 ? pad_to : lds, stream>>>(S, C, Wk, R);
+    /* (a plan is a list of blocks) */
+    launch_primary(kernel, R.plan ? dim3(R.plan_len) : grid, lds < pad_to && pad_to <= 65536 ? pad_to : lds, stream, S, C, Wk, R, ev0, ev1);
 }
 #else
 void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevRows &R,
-                       bool stats, bool blinn, hipStream_t stream, const RtJitKernels *jit)
+                       bool stats, bool blinn, hipStream_t stream, const RtJitKernels *jit, hipEvent_t ev0, hipEvent_t ev1)
 {
     const dim3 grid((C.W + 31u) / 32u, R.ntiles);
     const size_t lds = rt_scene_lds_bytes(S);
     if (jit && !stats && !blinn) {
-        launch_module(jit->primary, R.plan ? dim3(R.plan_len) : grid, lds, stream, S, C, Wk, R);
+        launch_module(jit->primary, R.plan ? dim3(R.plan_len) : grid, lds, stream, S, C, Wk, R, ev0, ev1);
         return;
     }
     const bool grid_scene = S.nSph > RT_TILE_SPHERES;
@@ -2722,10 +2735,7 @@ void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk,
             grid_scene ? (stats ? k_primary<true, true, false, 0, true> : k_primary<true, false, false, 0, true>)
             : S.tabInLds ? (stats ? k_primary<false, true, true, 0, true> : k_primary<false, false, true, 0, true>)
                          : (stats ? k_primary<false, true, false, 0, true> : k_primary<false, false, false, 0, true>);
-        if (R.plan)
-            kernel<<<R.plan_len, RT_BLOCK, lds, stream>>>(S, C, Wk, R);
-        else
-            kernel<<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, R);
+        launch_primary(kernel, R.plan ? dim3(R.plan_len) : grid, lds, stream, S, C, Wk, R, ev0, ev1);
         return;
     }
     /* three scene classes: small (everything in LDS), mid (spheres in LDS, tables in HBM), grid (spheres in HBM) */
@@ -2738,10 +2748,7 @@ void rt_launch_primary(const DevScene &S, const DevCamera &C, const DevWork &Wk,
      * blocks per CU instead of seven, i.e. a free block slot (LDS, 80 VGPRs) on every CU for the kernels of
      * a tail stream, which otherwise get in only when a block of this kernel retires */
     static const size_t pad_to = [] { const char *e = getenv("RT_HIP_PRIMARY_LDS"); return e ? (size_t)atol(e) : 0; }();
-    if (R.plan)
-        kernel<<<R.plan_len, RT_BLOCK, lds < pad_to && pad_to <= 65536 ? pad_to : lds, stream>>>(S, C, Wk, R);
-    else
-        kernel<<<grid, RT_BLOCK, lds < pad_to && pad_to <= 65536 ? pad_to : lds, stream>>>(S, C, Wk, R);
+    launch_primary(kernel, R.plan ? dim3(R.plan_len) : grid, lds < pad_to && pad_to <= 65536 ? pad_to : lds, stream, S, C, Wk, R, ev0, ev1);
 }
 #endif
 
