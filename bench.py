@@ -178,7 +178,7 @@ def small_scene_line(dev, numerics, numerics_name, cfg="syn64", frames=20):
     ms, n, rays, t0 = 0.0, 0, 0, 0.0
     for i in range(6 + frames):
         if i == 6:
-            g.set_timing(True)
+            g.set_timing(2)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
         g.render_rows(cam, frame.data_ptr(), 0, 0, H, 0)
@@ -381,8 +381,12 @@ def main():
     for i in range(warmup):
         pipe.submit(i)
         pipe.collect(i)
+    # k_primary's events: on the shared render stream the kernel's own start and end (what rocprofv3 reports); with a
+    # stream per frame - small frames, ranks of a split frame: the host is what bounds those - the cheaper pair around
+    # the dispatch (there the kernel shares the GPU with its neighbours' kernels and its time says little anyway)
+    timing_mode = 0 if os.environ.get("RT_BENCH_NO_K0_EVENTS") else (1 if args.overlap else 2)
     for c in ctxs:
-        c.set_timing(not os.environ.get("RT_BENCH_NO_K0_EVENTS"))  # (development: the run without the events)
+        c.set_timing(timing_mode)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -524,7 +528,7 @@ def main():
             # 30 frames, one at a time: k_primary alone on the GPU (in the timed region above it shares the GPU with
             # the previous frame's tail, which the tail stream lets in: throughput wins, the kernel's own time loses)
             def one_at_a_time(g):
-                g.set_timing(True)
+                g.set_timing(2)
                 frame = pipe.gathers[0].frame
                 ms, n, tg = 0.0, 0, 0.0
                 for i in range(10 + 30):

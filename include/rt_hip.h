@@ -403,7 +403,9 @@ void rt_hip_ctx_set_graph(rt_hip_ctx *ctx, int enable);
  * block_columns * tile_rows entries (both below 32768).  No counterpart in the reference. */
 void rt_launch_plan_order(const uint32_t *wave_ticks, uint32_t block_columns, uint32_t tile_rows, uint32_t *plan);
 
-/* Bracket the fused primary kernel with HIP events on the render stream (k0_ms). */
+/* Time the fused primary kernel (k0_ms, k0_launches).  enable = 1: two HIP events recorded around its launch on the
+ * render stream (they bracket the dispatch packet: the kernel plus its queue latency); 2: events that take the kernel's
+ * own start and end (hipExtLaunchKernel) - what a profiler reports, but ~25 us of host time a launch; 0: off. */
 void rt_hip_ctx_set_timing(rt_hip_ctx *ctx, int enable);
 /* Primary samples per image batch, as given (0 = automatic: what the queues hold).  A batch that outgrows the
  * queues is abandoned, halved and rendered again by rt_hip_finish. */

@@ -163,7 +163,8 @@ class Context:
         check(load().rt_hip_scene_upload(self._h, C.byref(view)), "rt_hip_scene_upload")
 
     def set_timing(self, on):
-        load().rt_hip_ctx_set_timing(self._h, int(bool(on)))
+        """False / 0: off; True / 1: HIP events around k_primary's dispatch; 2: the kernel's own start and end (rt_hip_ctx_set_timing)"""
+        load().rt_hip_ctx_set_timing(self._h, int(on))
 
     def set_shading(self, model):
         """SHADE_PHONG (get_shade_color_phong, what the reference calls) or SHADE_PHONGBLINN (its unused

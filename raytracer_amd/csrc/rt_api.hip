@@ -102,7 +102,7 @@ struct rt_hip_ctx {
     std::vector<Batch> batches;      /* batches in flight (enqueued, not yet checked) */
     std::vector<Batch> todo;         /* batches still to enqueue                      */
     /* options */
-    bool timing = false;
+    int timing = 0; /* rt_hip_ctx_set_timing: 0 off, 1 events around the dispatch, 2 the kernel's own start and end */
     bool no_shape = false; /* generic kernels only (survives scene uploads) */
     /* kernels compiled at run time for the scene's shape (rt_jit.cpp, rt_hip_ctx_set_jit): the policy, the frames
      * submitted since the scene (or the policy) changed, and what this frame launches (nullptr: the library's own) */
@@ -363,14 +363,14 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
     if (cut && c->tail_pending) /* the queues and node pool are shared with this context's previous batch */
         HIP_TRY(hipStreamWaitEvent(st, c->tail_done, 0));
     /* the counter block is zero: k_publish at the end of its last use left it so */
-    const bool timed = c->timing && !stats && !c->capturing;
+    const bool timed = c->timing != 0 && !stats && !c->capturing;
     if (timed) {
         hipEvent_t e0, e1;
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
         c->ev.push_back(e0);
         c->ev.push_back(e1);
-        if (jobs_path(c, stats)) /* (several kernels: bracketed; the fused k_primary takes the events itself) */
+        if (jobs_path(c, stats) || c->timing == 1) /* (the job pipeline's level 0 is several kernels: always bracketed) */
             HIP_TRY(hipEventRecord(e0, st));
     }
     /* the tolerance build has the plain Phong kernels only: instrumented and phong-blinn renders run the exact ones */
@@ -413,12 +413,16 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
     }
     if (R.plan)
         c->stats.planned_launches++;
-    /* timed: the kernel's own start and end (hipExtLaunchKernel), not two events around its dispatch */
-    hipEvent_t t0 = timed ? c->ev[c->ev.size() - 2] : nullptr, t1 = timed ? c->ev.back() : nullptr;
+    /* timing 2: the kernel's own start and end (hipExtLaunchKernel) instead of two events around its dispatch, which read
+     * its queue latency too - but cost the host ~25 us a launch, which frames of under 0.1 ms cannot afford (timing 1) */
+    const bool own = timed && c->timing == 2;
+    hipEvent_t t0 = own ? c->ev[c->ev.size() - 2] : nullptr, t1 = own ? c->ev.back() : nullptr;
     if (fast)
         rt_launch_primary_fast(c->S, c->C, Wk, R, st, c->jit_cur, t0, t1);
     else
         rt_launch_primary(c->S, c->C, Wk, R, stats, c->shading == RT_SHADE_PHONGBLINN, st, c->jit_cur, t0, t1);
+    if (timed && !own)
+        HIP_TRY(hipEventRecord(c->ev.back(), st));
     const bool early = c->early_alias && !stats && c->d_argb && !c->job.interleaved;
     const size_t early_off = (size_t)R.out_first * c->C.W;
     const uint32_t early_rows = (!c->job.interleaved && R.y_first + R.ntiles * 8u > R.y_limit) ? R.y_limit - R.y_first : R.ntiles * 8u;
@@ -1168,7 +1172,7 @@ void rt_hip_ctx_set_launch_plan(rt_hip_ctx *c, int enable)
 void rt_hip_ctx_set_timing(rt_hip_ctx *c, int enable)
 {
     if (c)
-        c->timing = enable != 0;
+        c->timing = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
 }
 
 int rt_hip_ctx_set_tail_stream(rt_hip_ctx *c, void *stream)
@@ -2014,11 +2018,11 @@ int rt_hip_finish(rt_hip_ctx *c, rt_hip_stats *stats)
         int rc = ctx_set_device(c);
         if (rc)
             return rc;
-        const bool was_timing = c->timing;
+        const int was_timing = c->timing;
         /* only the first round is timed; re-rendered batches are not */
         std::vector<hipEvent_t> ev;
         ev.swap(c->ev);
-        c->timing = false;
+        c->timing = 0;
         rc = drain(c);
         if (rc && rc != RT_E_OVERFLOW)
             c->counters_dirty = true;
