@@ -121,6 +121,8 @@ struct rt_hip_ctx {
      * copy of the batch's rows leaves for the host behind it, beside the levels and folds, and k_resolve - which waits
      * for that copy - stores the pixels it finishes both to the device frame and straight into the host's. */
     uint32_t *early_host = nullptr, *early_alias = nullptr; /* host address, device address of the same memory */
+    uint8_t *early_tiles = nullptr; /* pinned host copy of tile_done, made with the early copy of a one-batch frame (or nullptr) */
+    uint32_t early_tiles_n = 0;     /* flags it holds after early_done (0: none this frame) */
     hipStream_t early_stream = nullptr;
     hipEvent_t early_from = nullptr, early_done = nullptr;
     hipEvent_t head_done = nullptr, tail_done = nullptr;
@@ -431,6 +433,13 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
         HIP_TRY(hipStreamWaitEvent(c->early_stream, c->early_from, 0));
         HIP_TRY(hipMemcpyAsync(c->early_host + early_off, c->d_argb + early_off, (size_t)early_rows * c->C.W * sizeof(uint32_t),
                                hipMemcpyDeviceToHost, c->early_stream));
+        /* ... and, when the batch is the whole frame, which tiles those final pixels are: the host moves the tile rows
+         * that are final throughout into the caller's buffer while the levels still run (rt_hip_render) */
+        c->early_tiles_n = 0;
+        if (c->early_tiles && R.tile_done && R.ntiles == c->job.ntiles) {
+            c->early_tiles_n = R.ntiles * ((c->C.W + 31u) / 32u) * (RT_BLOCK / 64u);
+            HIP_TRY(hipMemcpyAsync(c->early_tiles, R.tile_done, c->early_tiles_n, hipMemcpyDeviceToHost, c->early_stream));
+        }
         HIP_TRY(hipEventRecord(c->early_done, c->early_stream));
     }
     auto to_tail = [&]() -> int {
@@ -2123,6 +2132,8 @@ int staged_copy_back(void *dst, const void *d_src, size_t bytes)
 namespace {
 uint32_t *g_hargb = nullptr, *g_hargb_dev = nullptr; /* pinned + mapped frame, its device address */
 size_t g_hargb_px = 0;
+uint8_t *g_tiles = nullptr; /* pinned: k_primary's flags of the tiles it finished (rt_hip_ctx::early_tiles) */
+size_t g_tiles_n = 0;
 
 class CopyPool { /* persistent helpers: each copies a slice; they spin briefly between jobs (frames come back to back), then sleep */
 public:
@@ -2166,7 +2177,8 @@ private:
     CopyPool()
     {
         const char *e = getenv("RT_HIP_COPY_THREADS");
-        int n = e && *e ? atoi(e) : 4;
+        const int hw = (int)std::thread::hardware_concurrency();
+        int n = e && *e ? atoi(e) : (hw >= 16 ? 8 : (hw >= 8 ? 4 : 2)); /* (a 1080p frame: 0.177 / 0.117 / 0.066 / 0.080 ms with 2 / 4 / 8 / 12) */
         n = n < 1 ? 1 : (n > 16 ? 16 : n);
         for (int i = 1; i < n; ++i)
             workers_.emplace_back([this, i] { run(i); });
@@ -2331,16 +2343,64 @@ int rt_hip_render(const rt_scene *scene, const rt_camera *cam, rt_framebuffer *f
     }
     g_ctx->early_host = mapped ? g_hargb : nullptr;
     g_ctx->early_alias = mapped ? g_hargb_dev : nullptr;
+    const uint32_t tile_rows = (fb->nrows + 7u) / 8u, tiles_per_row = ((fb->width + 31u) / 32u) * (RT_BLOCK / 64u);
+    if (mapped && (size_t)tile_rows * tiles_per_row > g_tiles_n) {
+        if (g_tiles)
+            (void)hipHostFree(g_tiles);
+        g_tiles = nullptr;
+        g_tiles_n = 0;
+        HIP_TRY(hipHostMalloc((void **)&g_tiles, (size_t)tile_rows * tiles_per_row, hipHostMallocPortable));
+        g_tiles_n = (size_t)tile_rows * tiles_per_row;
+    }
+    g_ctx->early_tiles = mapped ? g_tiles : nullptr;
+    g_ctx->early_tiles_n = 0;
     t_buffers = since();
     rc = rt_hip_render_rows(g_ctx, cam, d_argb, d_rad, fb->row0, fb->nrows, nullptr);
+    /* While the levels of the ray tree still run: the tile rows whose every tile k_primary finished (their pixels
+     * are in the mapped frame once the early copy is through) move into the caller's buffer now, the others after
+     * the frame.  Config 2: 40 % of the rows; the copy after the frame shrinks accordingly. */
+    std::vector<uint8_t> moved(tile_rows, 0);
+    if (!rc && mapped && g_ctx->early_tiles_n == tile_rows * tiles_per_row && g_ctx->batches.size() == 1 &&
+        hipEventSynchronize(g_ctx->early_done) == hipSuccess) {
+        for (uint32_t t = 0; t < tile_rows;) {
+            auto final_row = [&](uint32_t r) {
+                const uint8_t *f = g_tiles + (size_t)r * tiles_per_row;
+                for (uint32_t k = 0; k < tiles_per_row; ++k)
+                    if (f[k] != 1u)
+                        return false;
+                return true;
+            };
+            if (!final_row(t)) {
+                ++t;
+                continue;
+            }
+            uint32_t e = t;
+            while (e < tile_rows && final_row(e))
+                moved[e++] = 1;
+            const uint32_t r0 = fb->row0 + t * 8u, r1 = fb->row0 + (e * 8u < fb->nrows ? e * 8u : fb->nrows);
+            CopyPool::get().copy(fb->argb + (size_t)r0 * fb->width, g_hargb + (size_t)r0 * fb->width, (size_t)(r1 - r0) * fb->width * sizeof(uint32_t));
+            t = e;
+        }
+    }
     if (!rc)
         rc = rt_hip_finish(g_ctx, nullptr);
     t_render = since();
     if (!rc && fb->nrows) {
         const size_t off = (size_t)fb->row0 * fb->width, cnt = (size_t)fb->nrows * fb->width;
-        if (mapped)
-            CopyPool::get().copy(fb->argb + off, g_hargb + off, cnt * sizeof(uint32_t));
-        else
+        if (mapped) {
+            for (uint32_t t = 0; t < tile_rows;) { /* the runs of tile rows that have not been moved yet */
+                if (moved[t]) {
+                    ++t;
+                    continue;
+                }
+                uint32_t e = t;
+                while (e < tile_rows && !moved[e])
+                    ++e;
+                const uint32_t r0 = fb->row0 + t * 8u, r1 = fb->row0 + (e * 8u < fb->nrows ? e * 8u : fb->nrows);
+                CopyPool::get().copy(fb->argb + (size_t)r0 * fb->width, g_hargb + (size_t)r0 * fb->width, (size_t)(r1 - r0) * fb->width * sizeof(uint32_t));
+                t = e;
+            }
+        } else
             rc = staged_copy_back(fb->argb + off, d_argb + off, cnt * sizeof(uint32_t));
         if (!rc && fb->radiance)
             rc = staged_copy_back(fb->radiance + 3 * off, d_rad + 3 * off, cnt * 3 * sizeof(float));
