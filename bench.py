@@ -554,20 +554,26 @@ def main():
             if builtin:
                 # the same frames with the kernels any OTHER scene gets: first the generic ones (counts are run-time
                 # values), which such a scene's first frames take, then the ones compiled at run time for the scene's
-                # counts (rt_jit.cpp), which its later frames take
-                g.set_specialization(False)
-                g.set_jit(rt.JIT_OFF)
+                # counts (rt_jit.cpp), which its later frames take.  A context of its own each: a launch plan is made of
+                # the times the tiles took with the kernels that will follow it.
+                def other_kernels(jit_mode):
+                    h = rt.Context(device=local_rank)
+                    h.upload(scene)
+                    h.set_numerics(numerics)
+                    h.set_launch_plan(args.launch_plan == "on")
+                    h.set_specialization(False)
+                    h.set_jit(jit_mode)
+                    r = one_at_a_time(h)
+                    r["compile_seconds"] = h.jit_status()[1] if jit_mode != rt.JIT_OFF else None
+                    h.close()
+                    return r
                 out["generic_kernels"] = dict(
-                    one_at_a_time(g), note="30 frames, one at a time, with the library's kernels for any scene shape "
-                                           "(rt_hip_ctx_set_specialization(ctx, 0), rt_hip_ctx_set_jit(ctx, RT_JIT_OFF))")
-                g.set_jit(rt.JIT_NOW_ANY)
+                    other_kernels(rt.JIT_OFF), note="30 frames, one at a time, with the library's kernels for any scene shape "
+                                                    "(rt_hip_ctx_set_specialization(ctx, 0), rt_hip_ctx_set_jit(ctx, RT_JIT_OFF))")
                 out["run_time_kernels"] = dict(
-                    one_at_a_time(g), note="30 frames, one at a time, with kernels compiled at run time for this scene's "
-                                           "counts as for any other small scene (rt_hip_ctx_set_jit(ctx, RT_JIT_NOW_ANY): "
-                                           "the library's own kernels for the reference's shape are not used)",
-                    compile_seconds=g.jit_status()[1])
-                g.set_jit(rt.JIT_AUTO)
-                g.set_specialization(True)
+                    other_kernels(rt.JIT_NOW_ANY), note="30 frames, one at a time, with kernels compiled at run time for this scene's "
+                                                        "counts as for any other small scene (rt_hip_ctx_set_jit(ctx, RT_JIT_NOW_ANY): "
+                                                        "the library's own kernels for the reference's shape are not used)")
             elif not grid_scene and args.jit != "off":
                 st_, sec_, _ = g.jit_status()
                 out["run_time_kernels"] = {"state": st_, "compile_seconds": sec_,
