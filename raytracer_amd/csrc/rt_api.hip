@@ -248,7 +248,7 @@ bool jobs_path(const rt_hip_ctx *c, bool stats)
 {
     static const bool off = getenv("RT_HIP_NO_JOBS") != nullptr; /* development: the fused kernels for every scene */
     return !off && !c->no_jobs && c->S.grid != nullptr && (c->S.lgrid != nullptr || c->S.nLights == 0u) && !stats && c->shading == RT_SHADE_PHONG &&
-           c->S.nLights <= RT_JOBS_MAX_LIGHTS && c->S.nSph <= RT_CHUNK_MAX_SPHERES;
+           c->S.nLights <= RT_JOBS_MAX_LIGHTS && c->S.nSph <= RT_CHUNK_MAX_SPHERES && c->S.nObj <= RT_CHUNK_MAX_SPHERES; /* (the cell chunks' 21-bit object indices: build_grid) */
 }
 
 int ensure_level0(rt_hip_ctx *c, size_t npix, size_t spp2)
