@@ -1477,6 +1477,18 @@ void build_grid(const std::vector<float4> &sph, const rt_scene *sc, const std::v
                     }
                 }
             }
+            if (getenv("RT_HIP_GRID_STATS")) { /* development: how full the cells are */
+                size_t hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (size_t ci = 0; ci < cells; ++ci) {
+                    const uint32_t cnt = count[ci + 1] - count[ci];
+                    hist[cnt < 7u ? cnt : 7u]++;
+                }
+                fprintf(stderr, "rt_hip grid: %u x %u x %u = %zu cells, %zu listed spheres, %zu chunks; cells holding 0..6, 7+ spheres:",
+                        G.dim[0], G.dim[1], G.dim[2], cells, items.size(), chunks.size());
+                for (int i = 0; i < 8; ++i)
+                    fprintf(stderr, " %zu", hist[i]);
+                fprintf(stderr, "\n");
+            }
             words.assign(chunked ? (size_t)G.rec_words + chunks.size() * (sizeof(CellChunk) / sizeof(uint32_t)) : lists, 0u);
             memcpy(words.data(), &G, sizeof G);
             memcpy(words.data() + G.words, count.data(), (cells + 1) * sizeof(uint32_t));
