@@ -254,8 +254,8 @@ bool jobs_path(const rt_hip_ctx *c, bool stats)
 int ensure_level0(rt_hip_ctx *c, size_t npix, size_t spp2)
 {
     const size_t samples = npix * spp2, vis = samples * (c->S.nLights ? c->S.nLights : 1u);
-    if (samples > 0xFFFFFFFFull) {
-        set_err("a batch of %zu samples does not fit the job pipeline's 32-bit sample index", samples);
+    if (samples > 0x3FFFFFFFull) { /* (a word of the level-0 spawn log: sample | RT_HIT_*) */
+        set_err("a batch of %zu samples does not fit the job pipeline's 30-bit sample index", samples);
         return RT_E_INVALID;
     }
     if (samples > c->z_samples) {
@@ -1960,7 +1960,10 @@ static int submit(rt_hip_ctx *c, const rt_camera *cam, uint32_t *d_argb, float *
     c->pending = true;
     if (job.ntiles == 0)
         return 0;
-    const uint32_t per = tiles_per_batch(c, default_batch_samples(c));
+    uint64_t batch_samples = default_batch_samples(c);
+    if (jobs_path(c, job.stats) && batch_samples > 0x3FFFFFFFull)
+        batch_samples = 0x3FFFFFFFull; /* (the job pipeline's 30-bit sample index: ensure_level0) */
+    const uint32_t per = tiles_per_batch(c, batch_samples);
     const uint32_t most = per < job.ntiles ? per : job.ntiles;
     if (jobs_path(c, job.stats) && (rc = ensure_loopq(c)))
         return rc;
