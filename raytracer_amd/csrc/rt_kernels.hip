@@ -2944,7 +2944,10 @@ void RT_WRAP(rt_launch_jobs_hits)(const DevScene &S, const DevCamera &C, const D
                                   const DevLevel0 &Z, hipStream_t stream)
 {
     const dim3 grid((C.W + 31u) / 32u, R.ntiles);
-    k_hits<<<grid, RT_BLOCK, (size_t)S.nPolySlots * sizeof(float4), stream>>>(S, C, Wk, R, Z);
+    if (hits_with_shadows(S))
+        k_hits<true><<<grid, RT_BLOCK, (size_t)S.nPolySlots * sizeof(float4), stream>>>(S, C, Wk, R, Z);
+    else
+        k_hits<false><<<grid, RT_BLOCK, (size_t)S.nPolySlots * sizeof(float4), stream>>>(S, C, Wk, R, Z);
 }
 /* `expect`: hits per shard the level is expected to hold (0: unknown, or level 0 - a full resident set).  The
  * shadow rays of the level's hits, then (spawns: level != depth, raytrace.c:405,452) their child rays. */
@@ -2962,7 +2965,8 @@ void RT_WRAP(rt_launch_jobs_trace)(const DevScene &S, const DevCamera &C, const 
         /* a block's four waves work through ~2 rounds of jobs at least: a sparse level gets a small grid */
         const uint32_t slices = expect ? (uint32_t)((uint64_t)expect * kinds / (2u * RT_BLOCK)) + 1u : 0u;
         const uint32_t grid = queue_grid(Wk, (const void *)kernel, lds, slices ? slices * RT_BLOCK / 2u : 0u);
-        kernel<<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, R, Z, level);
+        if (!(level == 0u && shadow && hits_with_shadows(S))) /* (k_hits sent them, all but those for the loop below) */
+            kernel<<<grid, RT_BLOCK, lds, stream>>>(S, C, Wk, R, Z, level);
         /* ... and its rays that the grids could not take (few: a small grid), before the other kind of ray re-uses
          * the shard's loop queue */
         void (*loop)(DevScene, DevWork, DevLevel0, uint32_t) =
