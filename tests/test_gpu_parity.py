@@ -1153,3 +1153,50 @@ def test_big_scene_frames_against_the_reference(torch_cuda, make_scene, name):
     assert st.shadow_rays == c["ray_create"] - primary
     assert st.reflection_rays + st.transmission_rays == c["ray_tinypush"] - st.shadow_rays
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_lights", [1, 3])
+def test_hits_beyond_the_grids_reach_take_the_loop_over_every_sphere(torch_cuda, tmp_path, n_lights):
+    """A sphere cloud in a box of two units over a mirror floor of 120: nearly every hit on the floor lies beyond the
+    reach within which the grids are exact (1.5 box diagonals from the box's centre), so the floor's shadow rays and
+    reflection rays take the reference's own loop over every sphere (k_loop), queued by k_hits itself in a scene of one
+    light, by k_trace's shadow kernel in a scene of three.  Through the job pipeline, through the fused kernels and by
+    the oracle (libm powf rounding taken out): no pixel may differ in any bit."""
+    rng = np.random.default_rng(424242 + n_lights)
+    parts = ["desc\n{\n\t201\n\t%d\n}\n" % n_lights,
+             "camera\n{\nposition 0 4.5 0\nlookat 0 4.2 -1\nupvector 0 1 0\nprojection 45.0 1.0 200.0\n}\n",
+             "world\n{\nambient 1.0 1.0 1.0\nbackground .2 .3 .5\n}\n"]
+    for l in range(n_lights):
+        parts.append("pointlight\n{\nposition %g 9 %g\ndiffuse 1.0 1.0 1.0\nrange 150\n}\n" % (2.0 - 3.0 * l, 1.0 - 6.0 * l))
+    for k in range(200):
+        x, y, z = rng.uniform(-1, 1), rng.uniform(4, 6), rng.uniform(-9, -7)
+        kr, kt = (0.5, 0.0) if k % 3 == 0 else ((0.05, 0.8) if k % 3 == 1 else (0.0, 0.0))
+        parts.append("sphere\n{\nname S%d\nposition %r %r %r\nradius %r\ndiffuse %g %g %g\nspecular 1 1 1\n"
+                     "ka 0.1 kd 0.4 ks 0.3 ke 20 kr %g kt %g n 0.95\n}\n"
+                     % (k, x, y, z, rng.uniform(0.05, 0.2), rng.uniform(0.2, 1), rng.uniform(0.2, 1), rng.uniform(0.2, 1), kr, kt))
+    parts.append("polygon\n{\nname Floor\npoint 60 0 0\npoint 60 0 -120\npoint -60 0 -120\npoint -60 0 0\ndiffuse 0 1 0\n"
+                 "ka 0.1 kd 0.6 ks 0.2 ke 2 kr 0.4 kt 0 n 1\n}\n")
+    path = tmp_path / "far_floor.scene"
+    path.write_text("".join(parts))
+    sc = rt.load_scene(str(path))
+    cam = rt.prepare_camera(sc, 72, 56, 2, 4)
+    O.set_rounded_pow(True)
+    try:
+        a_o, r_o, _ = O.render(sc.c, cam, nthreads=16)
+    finally:
+        O.set_rounded_pow(False)
+    jobs = rt.Context(queue_cap=1 << 21)
+    jobs.upload(sc)
+    fused = rt.Context(queue_cap=1 << 21)
+    fused.upload(sc)
+    fused.set_pipeline(rt.PIPELINE_FUSED)
+    for k in range(2):
+        a, r, st = render_dev(torch_cuda, jobs, cam)
+        a_f, r_f, st_f = render_dev(torch_cuda, fused, cam)
+        assert np.array_equal(a, a_o) and np.array_equal(r.view(np.uint32), r_o.view(np.uint32)), (n_lights, k)
+        assert np.array_equal(a_f, a_o) and np.array_equal(r_f.view(np.uint32), r_o.view(np.uint32)), (n_lights, k)
+        assert (st.shadow_rays, st.reflection_rays, st.transmission_rays) == \
+               (st_f.shadow_rays, st_f.reflection_rays, st_f.transmission_rays)
+    jobs.close()
+    fused.close()
