@@ -2971,7 +2971,7 @@ void RT_WRAP(rt_launch_jobs_trace)(const DevScene &S, const DevCamera &C, const 
          * the shard's loop queue */
         void (*loop)(DevScene, DevWork, DevLevel0, uint32_t) =
             level == 0u ? (shadow ? k_loop<true, true> : k_loop<true, false>) : (shadow ? k_loop<false, true> : k_loop<false, false>);
-        loop<<<RT_SHARDS * 8u, RT_BLOCK, 0, stream>>>(S, Wk, Z, level);
+        loop<<<RT_SHARDS * 32u, RT_BLOCK, 0, stream>>>(S, Wk, Z, level); /* (a block per ray, 32 blocks a shard) */
     }
 }
 void RT_WRAP(rt_launch_jobs_shadefold)(const DevScene &S, const DevCamera &C, const DevWork &Wk, const DevLevel0 &Z,
