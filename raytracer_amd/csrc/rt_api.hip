@@ -1496,6 +1496,71 @@ void build_grid(const std::vector<float4> &sph, const rt_scene *sc, const std::v
                 memcpy(words.data() + G.words + cells + 1, items.data(), items.size() * sizeof(uint32_t));
             if (!chunks.empty())
                 memcpy(words.data() + G.rec_words, chunks.data(), chunks.size() * sizeof(CellChunk));
+            /* ... and all the spheres once more in GROUPS of 64 neighbours (Morton order of the centres) behind a ball
+             * around each group's centres, for k_loop (rt_jobs.inc): the rays the grid cannot take - a direction longer
+             * than unit: the reference's test then accepts what lies in a cone around the ray - test the 64 spheres of a
+             * group only when its ball can hold a sphere the test accepts.  GridHeader::pad_[0]: where the groups start
+             * (words, a multiple of 4), pad_[1]: how many; per group two float4 (centre and radius of the ball, the
+             * largest r*r), then 64 (centre, r*r) per group, then 64 sphere indices per group (RT_NONE: padding). */
+            {
+                std::vector<std::pair<uint32_t, uint32_t>> order(n);
+                for (size_t k = 0; k < n; ++k) {
+                    const double c[3] = {sph[k].x, sph[k].y, sph[k].z};
+                    uint32_t code = 0;
+                    for (int a = 0; a < 3; ++a) {
+                        double q = (c[a] - lo[a]) / ext[a];
+                        q = q < 0.0 ? 0.0 : (q > 1.0 ? 1.0 : q);
+                        uint32_t v = (uint32_t)(q * 1023.0);
+                        for (int b = 0; b < 10; ++b)
+                            code |= ((v >> b) & 1u) << (3 * b + a);
+                    }
+                    order[k] = {code, (uint32_t)k};
+                }
+                std::sort(order.begin(), order.end());
+                const size_t ngroups = (n + 63u) / 64u;
+                const size_t goff = (words.size() + 3u) & ~(size_t)3u;
+                words.resize(goff + ngroups * 8u + ngroups * 64u * 4u + ngroups * 64u, 0u);
+                float *grp = (float *)(words.data() + goff);
+                float *gsph = grp + ngroups * 8u;
+                uint32_t *gidx = (uint32_t *)(gsph + ngroups * 64u * 4u);
+                const bool no_cull = getenv("RT_HIP_NO_LOOP_CULL") != nullptr; /* development: every group's ball holds everything */
+                for (size_t g = 0; g < ngroups; ++g) {
+                    double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
+                    float r2max = 0.0f;
+                    const size_t cnt = std::min<size_t>(64u, n - g * 64u);
+                    for (size_t u = 0; u < cnt; ++u) {
+                        const float4 sp = sph[order[g * 64u + u].second];
+                        const double c[3] = {sp.x, sp.y, sp.z};
+                        for (int a = 0; a < 3; ++a) {
+                            blo[a] = fmin(blo[a], c[a]);
+                            bhi[a] = fmax(bhi[a], c[a]);
+                        }
+                        r2max = fmaxf(r2max, sp.w);
+                    }
+                    const float cf[3] = {(float)(0.5 * (blo[0] + bhi[0])), (float)(0.5 * (blo[1] + bhi[1])), (float)(0.5 * (blo[2] + bhi[2]))};
+                    double R = 0.0; /* (around the centre as the kernel reads it: the float) */
+                    for (size_t u = 0; u < 64u; ++u) {
+                        float *dst = gsph + (g * 64u + u) * 4u;
+                        if (u < cnt) {
+                            const uint32_t k = order[g * 64u + u].second;
+                            const float4 sp = sph[k];
+                            const double ddx = (double)sp.x - cf[0], ddy = (double)sp.y - cf[1], ddz = (double)sp.z - cf[2];
+                            R = fmax(R, sqrt(ddx * ddx + ddy * ddy + ddz * ddz));
+                            dst[0] = sp.x; dst[1] = sp.y; dst[2] = sp.z; dst[3] = sp.w;
+                            gidx[g * 64u + u] = k;
+                        } else {
+                            dst[0] = dst[1] = dst[2] = dst[3] = 0.0f;
+                            gidx[g * 64u + u] = RT_NONE;
+                        }
+                    }
+                    grp[g * 8u + 0] = cf[0]; grp[g * 8u + 1] = cf[1]; grp[g * 8u + 2] = cf[2];
+                    grp[g * 8u + 3] = no_cull ? 3.0e38f : (float)(R * (1.0 + 1e-6) + 1e-30);
+                    grp[g * 8u + 4] = r2max;
+                }
+                G.pad_[0] = (uint32_t)goff;
+                G.pad_[1] = (uint32_t)ngroups;
+                memcpy(words.data(), &G, sizeof G);
+            }
         }
     }
     grown.resize(n);

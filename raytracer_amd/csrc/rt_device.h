@@ -91,7 +91,7 @@ struct GridHeader {
     float centre[3]; /* of the box                       */
     float origin_reach2; /* a ray walks the grid only if its origin is within sqrt(this) of the centre */
     uint32_t rec_words;  /* where the cell chunks start: words from the grid's base, a multiple of 16; 0: none (too many spheres) */
-    uint32_t pad_[3];
+    uint32_t pad_[3];    /* [0], [1]: where the sphere GROUPS of k_loop start (words, a multiple of 4) and their number (build_grid); [2]: 0 */
 };
 /* The same cells once more as 64-byte CHUNKS of up to three spheres, for the walks of the job pipeline (rt_jobs.inc):
  * a lane gets a chunk with ONE round trip instead of three dependent ones (cellStart -> items -> sph), every walking

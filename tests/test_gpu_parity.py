@@ -1200,3 +1200,55 @@ def test_hits_beyond_the_grids_reach_take_the_loop_over_every_sphere(torch_cuda,
                (st_f.shadow_rays, st_f.reflection_rays, st_f.transmission_rays)
     jobs.close()
     fused.close()
+
+
+@pytest.mark.gpu
+def test_rays_longer_than_unit_find_their_spheres_behind_the_groups_balls(torch_cuda, tmp_path, monkeypatch):
+    """300 glass spheres of index 0.8 in a loose cloud: every ray that leaves one has a direction longer than unit (the
+    reference's refraction formula, raytrace.c:517-525), the grid cannot take it, and k_loop tests it against the spheres
+    of the groups whose ball its cone can touch.  Against the oracle (libm powf rounding taken out) bit for bit, against
+    the fused kernels (wave_loop_all: every sphere), and against a scene uploaded with the balls switched off
+    (RT_HIP_NO_LOOP_CULL: every group passes), frames and ray counts."""
+    rng = np.random.default_rng(8088)
+    parts = ["desc\n{\n\t301\n\t2\n}\n",
+             "camera\n{\nposition 0 4.5 2\nlookat 0 4.5 -1\nupvector 0 1 0\nprojection 45.0 1.0 200.0\n}\n",
+             "world\n{\nambient 1.0 1.0 1.0\nbackground .3 .4 .6\n}\n",
+             "pointlight\n{\nposition 3 12 2\ndiffuse 1.0 1.0 1.0\nrange 150\n}\n",
+             "pointlight\n{\nposition -6 9 -4\ndiffuse 0.6 0.6 0.9\nrange 150\n}\n"]
+    for k in range(300):
+        x, y, z = rng.uniform(-5, 5), rng.uniform(1, 8), rng.uniform(-16, -5)
+        parts.append("sphere\n{\nname S%d\nposition %r %r %r\nradius %r\ndiffuse %g %g %g\nspecular 1 1 1\n"
+                     "ka 0.1 kd 0.3 ks 0.3 ke 20 kr %g kt 0.8 n %g\n}\n"
+                     % (k, x, y, z, rng.uniform(0.2, 0.7), rng.uniform(0.2, 1), rng.uniform(0.2, 1), rng.uniform(0.2, 1),
+                        0.2 if k % 4 == 0 else 0.0, 0.8 if k % 2 else 1.25))
+    parts.append("polygon\n{\nname Floor\npoint 12 0 0\npoint 12 0 -24\npoint -12 0 -24\npoint -12 0 0\ndiffuse 0 1 0\n"
+                 "ka 0.1 kd 0.6 ks 0.2 ke 2 kr 0.3 kt 0 n 1\n}\n")
+    path = tmp_path / "glass.scene"
+    path.write_text("".join(parts))
+    sc = rt.load_scene(str(path))
+    cam = rt.prepare_camera(sc, 80, 60, 2, 6)
+    O.set_rounded_pow(True)
+    try:
+        a_o, r_o, _ = O.render(sc.c, cam, nthreads=16)
+    finally:
+        O.set_rounded_pow(False)
+    jobs = rt.Context(queue_cap=1 << 21)
+    jobs.upload(sc)
+    fused = rt.Context(queue_cap=1 << 21)
+    fused.upload(sc)
+    fused.set_pipeline(rt.PIPELINE_FUSED)
+    monkeypatch.setenv("RT_HIP_NO_LOOP_CULL", "1")
+    plain = rt.Context(queue_cap=1 << 21)
+    plain.upload(sc)
+    monkeypatch.delenv("RT_HIP_NO_LOOP_CULL")
+    for k in range(2):
+        a, r, st = render_dev(torch_cuda, jobs, cam)
+        a_f, r_f, st_f = render_dev(torch_cuda, fused, cam)
+        a_p, r_p, st_p = render_dev(torch_cuda, plain, cam)
+        assert np.array_equal(a, a_o) and np.array_equal(r.view(np.uint32), r_o.view(np.uint32)), k
+        assert np.array_equal(a_f, a_o) and np.array_equal(r_f.view(np.uint32), r_o.view(np.uint32)), k
+        assert np.array_equal(a_p, a_o) and np.array_equal(r_p.view(np.uint32), r_o.view(np.uint32)), k
+        rays = lambda s: (s.shadow_rays, s.reflection_rays, s.transmission_rays)
+        assert rays(st) == rays(st_f) == rays(st_p) and st.transmission_rays > 10000
+    for c in (jobs, fused, plain):
+        c.close()
