@@ -396,6 +396,28 @@ def test_argument_errors():
     ctx.close()
 
 
+def test_a_scene_of_more_polygons_than_a_blocks_lds_holds_is_refused_at_upload(tmp_path):
+    """The kernels keep every polygon's plane, vertices and edge equations in LDS (1024 slots of 16 bytes: some hundred
+    quads); a scene beyond that is refused by rt_hip_scene_upload with a message that says so - not at a kernel launch."""
+    parts = ["desc\n{\n\t241\n\t1\n}\n",
+             "camera\n{\nposition 0 4.5 2\nlookat 0 4.0 -1\nupvector 0 1 0\nprojection 45.0 1.0 200.0\n}\n",
+             "world\n{\nambient 1.0 1.0 1.0\nbackground .3 .4 .6\n}\n",
+             "pointlight\n{\nposition 2 10 1\ndiffuse 1.0 1.0 1.0\nrange 150\n}\n",
+             "sphere\n{\nname S\nposition 0 2 -8\nradius 1\ndiffuse 1 1 1\nspecular 1 1 1\nka 0.1 kd 0.4 ks 0.3 ke 20 kr 0 kt 0 n 1\n}\n"]
+    for ix in range(15):
+        for iz in range(16):
+            x0, x1, z0, z1 = -7.5 + ix, -6.5 + ix, -2.0 - iz, -3.0 - iz
+            parts.append("polygon\n{\nname F%d_%d\npoint %g 0 %g\npoint %g 0 %g\npoint %g 0 %g\npoint %g 0 %g\ndiffuse 0 1 0\n"
+                         "ka 0.1 kd 0.6 ks 0.2 ke 2 kr 0 kt 0 n 1\n}\n" % (ix, iz, x1, z0, x1, z1, x0, z1, x0, z0))
+    path = tmp_path / "tiles.scene"
+    path.write_text("".join(parts))
+    sc = rt.load_scene(str(path))
+    ctx = rt.Context(queue_cap=4096)
+    with pytest.raises(rt.RtHipError, match="LDS slots"):
+        ctx.upload(sc)
+    ctx.close()
+
+
 # ---------------------------------------------------------------------------------------------
 # device-resident interface
 # ---------------------------------------------------------------------------------------------
