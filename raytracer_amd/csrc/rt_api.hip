@@ -2323,7 +2323,9 @@ static int numerics_from_env(void)
     return -1; /* rejected by rt_hip_ctx_set_numerics */
 }
 
-int rt_hip_render(const rt_scene *scene, const rt_camera *cam, rt_framebuffer *fb)
+static uint64_t g_cap_floor = 0; /* queue entries rt_hip_render's context gets at least (raised when a frame did not fit) */
+
+static int render_locked(const rt_scene *scene, const rt_camera *cam, rt_framebuffer *fb)
 {
     if (!scene || !cam || !fb || !fb->argb) {
         set_err("null argument");
@@ -2334,7 +2336,6 @@ int rt_hip_render(const rt_scene *scene, const rt_camera *cam, rt_framebuffer *f
                 cam->frameBufferWidth, cam->frameBufferHeight);
         return RT_E_INVALID;
     }
-    std::lock_guard<std::mutex> lk(g_mu);
     int rc;
     /* RT_HIP_TIMES=1: where the call's time goes, to stderr (development; tools/one_shot.py) */
     static const bool times = getenv("RT_HIP_TIMES") != nullptr;
@@ -2364,6 +2365,8 @@ int rt_hip_render(const rt_scene *scene, const rt_camera *cam, rt_framebuffer *f
     /* queue capacity sized to the job: 2 entries per primary sample, 1 Mi .. default */
     const uint64_t samples = (uint64_t)fb->width * fb->nrows * cam->sqrtSpp * cam->sqrtSpp;
     uint64_t want = samples * 2 < (1ull << 20) ? (1ull << 20) : samples * 2;
+    if (want < g_cap_floor)
+        want = g_cap_floor;
     if (want > kDefaultCap)
         want = kDefaultCap;
     if (g_ctx && g_ctx->cap < want) {
@@ -2491,6 +2494,21 @@ int rt_hip_render(const rt_scene *scene, const rt_camera *cam, rt_framebuffer *f
     return rc;
 }
 
+int rt_hip_render(const rt_scene *scene, const rt_camera *cam, rt_framebuffer *fb)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (;;) {
+        const int rc = render_locked(scene, cam, fb);
+        /* The context holds two queue entries per sample of the frame (1 Mi at least).  One tile row of a small frame
+         * whose every hit spawns two rays can need more - 2^(depth + 1) nodes a sample: four times the room then,
+         * and the frame again, until it fits or the capacity is the library's default (raytrace() renders what it is
+         * handed, like the reference; a caller of the context interface picks its own capacity). */
+        if (rc != RT_E_OVERFLOW || !g_ctx || g_ctx->cap >= kDefaultCap)
+            return rc;
+        g_cap_floor = g_ctx->cap * 4u;
+    }
+}
+
 /* ---- the host-pointer path on several GPUs of this process -------------------------------- */
 
 namespace {
@@ -2535,7 +2553,7 @@ void scatter_blocks(void *host, const void *staged, size_t px_bytes, uint32_t W,
 }
 } // namespace
 
-int rt_hip_render_devices(const rt_scene *scene, const rt_camera *cam, rt_framebuffer *fb, const int *devices,
+static int render_devices_locked(const rt_scene *scene, const rt_camera *cam, rt_framebuffer *fb, const int *devices,
                           uint32_t ndevices)
 {
     if (!scene || !cam || !fb || !fb->argb || !devices || ndevices == 0 || ndevices > 64) {
@@ -2555,7 +2573,6 @@ int rt_hip_render_devices(const rt_scene *scene, const rt_camera *cam, rt_frameb
             set_err("device %d of the list does not exist (%d visible)", devices[r], have);
             return RT_E_INVALID;
         }
-    std::lock_guard<std::mutex> lk(g_mu);
     int before = 0;
     HIP_TRY(hipGetDevice(&before));
     struct Restore { /* the caller's current device comes back on every exit path */
@@ -2567,6 +2584,8 @@ int rt_hip_render_devices(const rt_scene *scene, const rt_camera *cam, rt_frameb
     const size_t local_px = (size_t)per * 8u * W;
     const uint64_t samples = (uint64_t)local_px * cam->sqrtSpp * cam->sqrtSpp;
     uint64_t want = samples * 2 < (1ull << 20) ? (1ull << 20) : samples * 2;
+    if (want < g_cap_floor)
+        want = g_cap_floor;
     if (want > kDefaultCap)
         want = kDefaultCap;
 
@@ -2650,6 +2669,22 @@ int rt_hip_render_devices(const rt_scene *scene, const rt_camera *cam, rt_frameb
             }
         }
     return rc;
+}
+
+int rt_hip_render_devices(const rt_scene *scene, const rt_camera *cam, rt_framebuffer *fb, const int *devices,
+                          uint32_t ndevices)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (;;) { /* (as rt_hip_render: a frame that does not fit the contexts' queues is rendered again with four times the room) */
+        const int rc = render_devices_locked(scene, cam, fb, devices, ndevices);
+        uint64_t cap = 0;
+        for (const DevSlot &s : g_slots)
+            if (s.ctx && s.ctx->cap > cap)
+                cap = s.ctx->cap;
+        if (rc != RT_E_OVERFLOW || cap == 0 || cap >= kDefaultCap)
+            return rc;
+        g_cap_floor = cap * 4u;
+    }
 }
 
 /* RT_HIP_DEVICES = "all" | "0,1,2,3": the device list raytrace() spreads a frame over (unset: the

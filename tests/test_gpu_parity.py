@@ -1274,3 +1274,44 @@ def test_rays_longer_than_unit_find_their_spheres_behind_the_groups_balls(torch_
         assert rays(st) == rays(st_f) == rays(st_p) and st.transmission_rays > 10000
     for c in (jobs, fused, plain):
         c.close()
+
+
+def bushy_scene_text(seed):
+    """a loose cloud of 1500 spheres of all sizes around the eye, a quarter each dull, mirror, glass and both"""
+    rng = np.random.default_rng(seed)
+    eye = (float(rng.uniform(-7.5, 7.5)), 4.5 + float(rng.uniform(-3.75, 3.75)), -8.0 + float(rng.uniform(-7.5, 7.5)))
+    parts = ["desc\n{\n\t1500\n\t1\n}\n",
+             "camera\n{\nposition %r %r %r\nlookat 0 4.5 -8\nupvector 0 1 0\nprojection 45.0 1.0 200.0\n}\n" % eye,
+             "world\n{\nambient 1.0 1.0 1.0\nbackground .3 .4 .6\n}\n",
+             "pointlight\n{\nposition 2 10 1\ndiffuse 1.0 1.0 1.0\nrange 150\n}\n"]
+    for k in range(1500):
+        x, y, z = rng.uniform(-7.5, 7.5), 4.5 + rng.uniform(-7.5, 7.5), -8.0 + rng.uniform(-7.5, 7.5)
+        kr, kt = [(0.0, 0.0), (0.5, 0.0), (0.05, 0.8), (0.3, 0.5)][int(rng.integers(0, 4))]
+        parts.append("sphere\n{\nname S%d\nposition %r %r %r\nradius %r\ndiffuse %g %g %g\nspecular 1 1 1\n"
+                     "ka 0.1 kd 0.4 ks 0.3 ke 20 kr %g kt %g n %g\n}\n"
+                     % (k, x, y, z, float(rng.uniform(0.02, 1.25)), *rng.uniform(0.2, 1, 3), kr, kt, float(rng.choice([0.8, 0.95, 1.0, 1.25]))))
+    return "".join(parts)
+
+
+def test_the_one_call_entry_grows_its_queues_for_a_tile_row_of_bushy_trees(torch_cuda, tmp_path):
+    """A cloud in which a tile row of a 33 x 16 frame at 9 samples a pixel and depth 8 makes more hits than a context of a
+    million queue entries holds for its shards (tools/fuzz_big.py found such a case, tools/bushy_probe.py this seed): such
+    a context says RT_E_OVERFLOW, which is what the context interface promises; the one call - rt_hip_render, raytrace() -
+    starts with that capacity and must render the frame all the same, with a roomier context, as the oracle does (libm
+    powf rounding taken out): raytrace() renders what it is given."""
+    path = tmp_path / "bushy.scene"
+    path.write_text(bushy_scene_text(22))
+    sc = rt.load_scene(str(path))
+    cam = rt.prepare_camera(sc, 33, 16, 3, 8)
+    small = rt.Context(queue_cap=1 << 20)
+    small.upload(sc)
+    with pytest.raises(rt.RtHipError, match="overflow on a single"):
+        render_dev(torch_cuda, small, cam)
+    small.close()
+    O.set_rounded_pow(True)
+    try:
+        a_o, r_o, cnt = O.render(sc.c, cam, nthreads=16)
+    finally:
+        O.set_rounded_pow(False)
+    argb, rad = rt.render(sc, cam)
+    assert np.array_equal(argb, a_o) and np.array_equal(rad.view(np.uint32), r_o.view(np.uint32))

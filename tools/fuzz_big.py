@@ -1,0 +1,69 @@
+"""development: random BIG scenes (a sphere grid: the job pipeline, csrc/rt_jobs.inc) as scene files - clouds of 130-1500
+spheres, glass of index 0.8 / 0.95 / 1 / 1.25 (rays longer than unit: k_loop behind its groups' balls), mirrors, 0-4
+quads near and far, 1-8 lights (k_hits sends the shadow rays of one or two), the eye outside, inside and far from the
+cloud - GPU against the oracle with libm's powf rounding taken out: every pixel bit-identical.
+usage: python tools/fuzz_big.py [cases] [seed] [first case rendered]"""
+import sys, time, tempfile, os; sys.path.insert(0, '.')
+import numpy as np, raytracer_amd as rt
+from oracle import oracle_py as O
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+O.set_rounded_pow(True)
+bad = 0
+t0 = time.time()
+tmp = tempfile.mkdtemp()
+for c in range(cases):
+    n_sph = int(rng.choice([130, 200, 400, 900, 1500]))
+    n_l = int(rng.choice([1, 1, 2, 2, 3, 5, 8]))
+    n_pol = int(rng.integers(0, 5))
+    ext = float(rng.choice([2.0, 6.0, 15.0]))
+    eye = [0.0, 4.5, 2.0]
+    mode = int(rng.integers(0, 4))
+    if mode == 1:   # inside the cloud
+        eye = [float(rng.uniform(-ext / 2, ext / 2)), 4.5 + float(rng.uniform(-ext / 4, ext / 4)), -8.0 + float(rng.uniform(-ext / 2, ext / 2))]
+    elif mode == 2: # far away
+        eye = [float(rng.normal(0, 30)), 4.5 + float(rng.normal(0, 10)), 60.0 + float(rng.normal(0, 30))]
+    parts = ["desc\n{\n\t%d\n\t%d\n}\n" % (n_sph + n_pol, n_l),
+             "camera\n{\nposition %r %r %r\nlookat 0 4.5 -8\nupvector 0 1 0\nprojection 45.0 1.0 200.0\n}\n" % tuple(eye),
+             "world\n{\nambient 1.0 1.0 1.0\nbackground .3 .4 .6\n}\n"]
+    for l in range(n_l):
+        parts.append("pointlight\n{\nposition %r %r %r\ndiffuse %g %g %g\nrange 150\n}\n"
+                     % (float(rng.uniform(-10, 10)), float(rng.uniform(2, 14)), float(rng.uniform(-16, 4)), *rng.uniform(0.3, 1, 3)))
+    rmax = ext / 12.0
+    for k in range(n_sph):
+        x, y, z = rng.uniform(-ext / 2, ext / 2), 4.5 + rng.uniform(-ext / 2, ext / 2), -8.0 + rng.uniform(-ext / 2, ext / 2)
+        m = int(rng.integers(0, 4))
+        kr, kt = [(0.0, 0.0), (0.5, 0.0), (0.05, 0.8), (0.3, 0.5)][m]
+        n = float(rng.choice([0.8, 0.95, 1.0, 1.25]))
+        parts.append("sphere\n{\nname S%d\nposition %r %r %r\nradius %r\ndiffuse %g %g %g\nspecular 1 1 1\n"
+                     "ka 0.1 kd 0.4 ks 0.3 ke %d kr %g kt %g n %g\n}\n"
+                     % (k, x, y, z, float(rng.uniform(0.02, rmax)), *rng.uniform(0.2, 1, 3), int(rng.choice([2, 20])), kr, kt, n))
+    for q in range(n_pol):
+        far = rng.random() < 0.5
+        h = (60.0 if far else ext)
+        y0 = 4.5 - ext / 2 - (0.2 if q == 0 else float(rng.uniform(0.2, 3.0)))
+        parts.append("polygon\n{\nname P%d\npoint %g %g %g\npoint %g %g %g\npoint %g %g %g\npoint %g %g %g\ndiffuse 0 1 0\n"
+                     "ka 0.1 kd 0.6 ks 0.2 ke 2 kr %g kt 0 n 1\n}\n"
+                     % (q, h, y0, -8 + h, h, y0, -8 - h, -h, y0, -8 - h, -h, y0, -8 + h, float(rng.choice([0.0, 0.4]))))
+    path = os.path.join(tmp, "s%d.scene" % c)
+    open(path, "w").write("".join(parts))
+    sc = rt.load_scene(path)
+    W, H = int(rng.integers(8, 48)), int(rng.integers(8, 36))
+    s, d = int(rng.integers(1, 4)), int(rng.integers(0, 9))
+    if c < first:
+        continue
+    cam = rt.prepare_camera(sc, W, H, s, d)
+    argb, rad = rt.render(sc, cam)
+    a_o, r_o, _ = O.render(sc.c, cam, nthreads=16)
+    differ = (rad.view(np.uint32) != r_o.view(np.uint32)).any(-1)
+    ok = not differ.any() and np.array_equal(argb, a_o)
+    argb2, rad2 = rt.render(sc, cam)
+    ok2 = np.array_equal(argb2, argb) and np.array_equal(rad2.view(np.uint32), rad.view(np.uint32))
+    if not (ok and ok2):
+        bad += 1
+    print("%s case %d: %dx%d s%d d%d sph=%d lights=%d quads=%d ext=%g eye-mode=%d differ=%d second-render-same=%s [%.0f s]"
+          % ("ok " if ok and ok2 else "BAD", c, W, H, s, d, n_sph, n_l, n_pol, ext, mode, int(differ.sum()), ok2, time.time() - t0), flush=True)
+print("%d bad of %d" % (bad, cases))
+sys.exit(1 if bad else 0)
