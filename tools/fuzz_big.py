@@ -55,7 +55,12 @@ for c in range(cases):
     if c < first:
         continue
     cam = rt.prepare_camera(sc, W, H, s, d)
-    argb, rad = rt.render(sc, cam)
+    try:
+        argb, rad = rt.render(sc, cam)
+    except rt.RtHipError as e:
+        bad += 1
+        print("BAD case %d: %dx%d s%d d%d sph=%d lights=%d quads=%d ext=%g eye-mode=%d: %s" % (c, W, H, s, d, n_sph, n_l, n_pol, ext, mode, str(e)[:120]), flush=True)
+        continue
     a_o, r_o, _ = O.render(sc.c, cam, nthreads=16)
     differ = (rad.view(np.uint32) != r_o.view(np.uint32)).any(-1)
     ok = not differ.any() and np.array_equal(argb, a_o)
