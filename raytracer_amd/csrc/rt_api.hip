@@ -386,12 +386,11 @@ int enqueue_batch(rt_hip_ctx *c, const Batch &b, bool stats)
         Z.npix = R.ntiles * 8u * c->C.W;
         Z.nsamples = Z.npix * c->C.sqrtSpp * c->C.sqrtSpp;
         const bool known = c->seen_valid;
-        uint32_t last = depth; /* deepest level that may hold hits */
-        if (known)
-            while (last > 0u && c->seen_hits[last] == 0u)
-                --last;
-        if (known && last < depth)
-            ++last; /* (one level of margin: an empty level's kernels return at once) */
+        /* Every level down to the depth asked for is launched, whatever the last frame of this shape held there: its
+         * sizes only choose the grids (an empty level's kernels return at once, ~30 us a level).  Launching only the
+         * levels that frame had used - plus one - lost the deeper hits of the next frame when that was another view:
+         * another row slab of the same height, a camera that moved (found by tools/fuzz_big.py, FUZZ_CTX=slabs). */
+        const uint32_t last = depth;
         (fast ? rt_launch_jobs_hits_fast : rt_launch_jobs_hits)(c->S, c->C, Wk, R, Z, st);
         for (uint32_t d = 0; d <= last; ++d) {
             const uint32_t expect = d == 0u ? 0u : known ? (c->seen_hits[d] ? c->seen_hits[d] : 1u) : 0u;

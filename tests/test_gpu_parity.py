@@ -1315,3 +1315,33 @@ def test_the_one_call_entry_grows_its_queues_for_a_tile_row_of_bushy_trees(torch
         O.set_rounded_pow(False)
     argb, rad = rt.render(sc, cam)
     assert np.array_equal(argb, a_o) and np.array_equal(rad.view(np.uint32), r_o.view(np.uint32))
+
+
+def test_a_contexts_next_view_is_not_cut_at_the_depth_of_its_last(torch_cuda, make_scene):
+    """A context remembers how many hits the levels of its last frame of a shape held - to size its launches, nothing
+    else.  (The job pipeline once launched only the levels that frame had used, plus one: a slab of sky followed by a slab
+    of the same height full of mirrors, or a camera that turned, lost every deeper hit.  tools/fuzz_big.py FUZZ_CTX=slabs.)
+    Config 4's scene at 160 x 120, depth 6: an 8-row band that sees nothing but the background, then the bands below it,
+    each against a context that has rendered nothing else - bit for bit - and the sky band once more at the end."""
+    sc = make_scene("c4")
+    sc.c.eyePos.y += 6.0  # (look over the walls: the top of the frame is sky)
+    cam = rt.prepare_camera(sc, 160, 120, 2, 6)
+    def fresh(r0):
+        c = rt.Context(queue_cap=1 << 22)
+        c.upload(sc)
+        a, r, st = render_dev(torch_cuda, c, cam, r0, 8)
+        c.close()
+        return a[r0:r0 + 8], r[r0:r0 + 8], st
+    bands = {r0: fresh(r0) for r0 in range(0, 120, 8)}
+    sky = [r0 for r0, (a, r, st) in bands.items() if st.shade_nodes == 0]
+    deep = [r0 for r0, (a, r, st) in bands.items() if st.reflection_rays + st.transmission_rays > 10 * 160 * 8]
+    assert sky and deep, (sky, deep)
+    ctx = rt.Context(queue_cap=1 << 22)
+    ctx.upload(sc)
+    for r0 in [sky[0]] + deep + [sky[0]] + sorted(bands):
+        a, r, st = render_dev(torch_cuda, ctx, cam, r0, 8)
+        want_a, want_r, want_st = bands[r0]
+        assert np.array_equal(a[r0:r0 + 8], want_a) and np.array_equal(r[r0:r0 + 8].view(np.uint32), want_r.view(np.uint32)), r0
+        assert (st.shadow_rays, st.reflection_rays, st.transmission_rays) == \
+               (want_st.shadow_rays, want_st.reflection_rays, want_st.transmission_rays), r0
+    ctx.close()

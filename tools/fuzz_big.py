@@ -54,21 +54,52 @@ for c in range(cases):
     s, d = int(rng.integers(1, 4)), int(rng.integers(0, 9))
     if c < first:
         continue
+    if os.environ.get("FUZZ_DUMP"):
+        os.environ["FUZZ_LAST_SCENE"] = path
+        os.environ["FUZZ_LAST_FRAME"] = "%d %d %d %d" % (W, H, s, d)
     cam = rt.prepare_camera(sc, W, H, s, d)
     try:
-        argb, rad = rt.render(sc, cam)
+        if os.environ.get("FUZZ_CTX"):  # the context interface: small queues (batches, halved batches), row slabs, the tolerance build never
+            import torch
+            sys.path.insert(0, "tests")
+            from test_gpu_parity import render_dev
+            fmode = os.environ.get("FUZZ_CTX")
+            qcap = int(rng.choice([1 << 14, 1 << 16, 1 << 18, 1 << 20, 0])); bs = int(rng.choice([0, 0, 1 << 10, 1 << 14, 1 << 30]))
+            if fmode == "slabs":
+                qcap, bs = 1 << 22, 0
+            ctx = rt.Context(queue_cap=qcap)
+            ctx.upload(sc)
+            if os.environ.get("FUZZ_FUSED"):
+                ctx.set_pipeline(rt.PIPELINE_FUSED)
+            if bs:
+                ctx.set_batch_samples(bs)
+            argb = np.zeros((H, W), np.uint32); rad = np.zeros((H, W, 3), np.float32)
+            cuts = sorted(set([0, H] + ([] if fmode == "caps" else [int(x) for x in rng.integers(0, H + 1, int(rng.integers(0, 3)))])))
+            extra = " cap=%d batch=%d cuts=%s" % (qcap, bs, cuts)
+            for r0, r1 in zip(cuts[:-1], cuts[1:]):
+                a_, r_, st_ = render_dev(torch, ctx, cam, r0, r1 - r0)
+                argb[r0:r1] = a_[r0:r1]; rad[r0:r1] = r_[r0:r1]
+            ctx.close()
+        else:
+            argb, rad = rt.render(sc, cam)
     except rt.RtHipError as e:
+        if os.environ.get("FUZZ_CTX") and "overflow on a single" in str(e):  # a context of an explicit, tiny capacity: what the interface promises
+            print("cap  case %d: %s" % (c, str(e)[-90:]), flush=True)
+            continue
         bad += 1
         print("BAD case %d: %dx%d s%d d%d sph=%d lights=%d quads=%d ext=%g eye-mode=%d: %s" % (c, W, H, s, d, n_sph, n_l, n_pol, ext, mode, str(e)[:120]), flush=True)
         continue
     a_o, r_o, _ = O.render(sc.c, cam, nthreads=16)
     differ = (rad.view(np.uint32) != r_o.view(np.uint32)).any(-1)
     ok = not differ.any() and np.array_equal(argb, a_o)
-    argb2, rad2 = rt.render(sc, cam)
+    argb2, rad2 = (argb, rad) if os.environ.get("FUZZ_CTX") else rt.render(sc, cam)
     ok2 = np.array_equal(argb2, argb) and np.array_equal(rad2.view(np.uint32), rad.view(np.uint32))
     if not (ok and ok2):
         bad += 1
-    print("%s case %d: %dx%d s%d d%d sph=%d lights=%d quads=%d ext=%g eye-mode=%d differ=%d second-render-same=%s [%.0f s]"
-          % ("ok " if ok and ok2 else "BAD", c, W, H, s, d, n_sph, n_l, n_pol, ext, mode, int(differ.sum()), ok2, time.time() - t0), flush=True)
+    print("%s case %d: %dx%d s%d d%d sph=%d lights=%d quads=%d ext=%g eye-mode=%d differ=%d second-render-same=%s [%.0f s]%s"
+          % ("ok " if ok and ok2 else "BAD", c, W, H, s, d, n_sph, n_l, n_pol, ext, mode, int(differ.sum()), ok2, time.time() - t0, extra if os.environ.get("FUZZ_CTX") else ""), flush=True)
+    if not ok and os.environ.get("FUZZ_CTX"):
+        ys, xs = np.nonzero(differ)
+        print("    differing pixels (y, x):", list(zip(ys.tolist(), xs.tolist()))[:12], flush=True)
 print("%d bad of %d" % (bad, cases))
 sys.exit(1 if bad else 0)
