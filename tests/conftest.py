@@ -25,6 +25,16 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def pins():
+    """tests/golden/pins.npz: 32 768 + 8192 pixels of configs 4 and 5 at full frame size, from the untouched reference
+    (tests/golden/make_golden_pins.py)."""
+    with open(os.path.join(GOLDEN_DIR, "pins.json")) as f:
+        meta = json.load(f)
+    arrays = np.load(os.path.join(GOLDEN_DIR, "pins.npz"), allow_pickle=False)
+    return meta, arrays
+
+
+@pytest.fixture(scope="session")
 def make_scene(golden):
     """name -> raytracer_amd.Scene, from the scene table stored with the fixtures."""
     import raytracer_amd as rt

@@ -84,6 +84,19 @@ def test_sparse_pixels_of_full_size_configs(golden, make_scene, idx):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("idx,step", [(0, 4), (1, 32)])
+def test_more_pins_of_the_sphere_clouds_at_full_size(pins, make_scene, idx, step):
+    """tests/golden/pins.npz (the reference's get_pixel_color on 32 768 pixels of config 4 and 8192 of config 5 at
+    their real frame sizes): every 4th / 32nd of them through the oracle, bit for bit (the GPU suite takes them all)."""
+    meta, arrays = pins
+    sp = meta["pins"][idx]
+    sc = make_scene(sp["scene"])
+    cam = O.prepare_camera(sc.c, sp["W"], sp["H"], sp["sqrtSpp"], sp["depth"])
+    xy, want = arrays[sp["key"] + "_xy"][::step], arrays[sp["key"] + "_rad"][::step]
+    got = np.stack([O.pixel(sc.c, cam, int(x), int(y)) for x, y in xy])
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def test_survey_radiance_samples(golden):
     """SURVEY.md appendix C.3 (printed %.9g by the survey's own harness)."""
     _, arrays = golden
