@@ -659,6 +659,73 @@ def test_rows_of_pins_of_the_sphere_clouds_at_full_size(torch_cuda, pins, make_s
     ctx.close()
 
 
+def test_config_4_whole_by_every_entry_point_on_the_pins(torch_cuda, pins, make_scene):
+    """BASELINE config 4 as a WHOLE frame (3840x2160, 16 spp, depth 8; 133 M samples) by the call the reference's main()
+    makes (rt_hip_render), by the same call over a device list (rt_hip_render_devices: three shares, this box's one
+    GPU named three times) and as the cyclic 8-row blocks of a rank of eight, every rank in turn
+    (rt_hip_render_interleaved + rt_hip_deinterleave: what bench.py runs for N = 8): the three frames are one frame,
+    and its 32 768 pinned pixels are the untouched reference's."""
+    torch = torch_cuda
+    meta, arrays = pins
+    sp = meta["pins"][0]
+    W, H = sp["W"], sp["H"]
+    sc = make_scene("c4")
+    cam = rt.prepare_camera(sc, W, H, sp["sqrtSpp"], sp["depth"])
+    a1, r1 = rt.render(sc, cam)
+    a2, r2 = rt.render(sc, cam, devices=[0, 0, 0])
+    assert np.array_equal(a1, a2) and np.array_equal(r1.view(np.uint32), r2.view(np.uint32))
+    ctx = rt.Context()
+    ctx.upload(sc)
+    nph, kmax = 8, ((H + 7) // 8 + 7) // 8
+    parts_a = torch.zeros((nph, kmax * 8, W), dtype=torch.int32, device="cuda")
+    parts_r = torch.zeros((nph, kmax * 8, W, 3), dtype=torch.float32, device="cuda")
+    for ph in range(nph):
+        ctx.render_interleaved(cam, parts_a[ph].data_ptr(), parts_r[ph].data_ptr(), ph, nph)
+        ctx.finish()
+    ctx.close()
+    frame = torch.full((H, W), -1, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.load().rt_hip_deinterleave(parts_a.data_ptr(), frame.data_ptr(), W, H, nph, None), "rt_hip_deinterleave")
+    torch.cuda.synchronize()
+    assert np.array_equal(frame.cpu().numpy().view(np.uint32), a1)
+    r3 = parts_r.view(nph, kmax, 8, W, 3).permute(1, 0, 2, 3, 4).reshape(-1, W, 3)[:H].cpu().numpy()
+    assert np.array_equal(r3.view(np.uint32), r1.view(np.uint32))
+    xy, want = arrays[sp["key"] + "_xy"], arrays[sp["key"] + "_rad"]
+    got = r1[xy[:, 1], xy[:, 0]]
+    rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-3)
+    assert (rel <= 1e-4).all()
+    assert int((got.view(np.uint32) == want.view(np.uint32)).all(-1).sum()) >= len(xy) - 16
+
+
+def test_config_5_whole_at_full_size_a_rank_of_eight_at_a_time_on_the_pins(torch_cuda, pins, make_scene):
+    """BASELINE config 5 at its real size (7680x4320, 64 spp = 2.1 G samples, depth 16, 16 384 spheres, 8 lights) as
+    the WHOLE frame: the cyclic 8-row blocks of each rank of eight in turn on this box's one GPU
+    (rt_hip_render_interleaved, a context that sizes itself), put together as the all-gather's host does; the frame's
+    8192 pinned pixels are the untouched reference's, and its rays are counted."""
+    torch = torch_cuda
+    meta, arrays = pins
+    sp = meta["pins"][1]
+    W, H = sp["W"], sp["H"]
+    sc = make_scene("c5")
+    cam = rt.prepare_camera(sc, W, H, sp["sqrtSpp"], sp["depth"])
+    ctx = rt.Context()
+    ctx.upload(sc)
+    nph, kmax = 8, ((H + 7) // 8 + 7) // 8
+    parts_a = torch.zeros((nph, kmax * 8, W), dtype=torch.int32, device="cuda")
+    parts_r = torch.zeros((nph, kmax * 8, W, 3), dtype=torch.float32, device="cuda")
+    primary = 0
+    for ph in range(nph):
+        ctx.render_interleaved(cam, parts_a[ph].data_ptr(), parts_r[ph].data_ptr(), ph, nph)
+        primary += ctx.finish().primary_rays
+    ctx.close()
+    assert primary == W * H * 64
+    frame = parts_r.view(nph, kmax, 8, W, 3).permute(1, 0, 2, 3, 4).reshape(-1, W, 3)[:H]
+    xy, want = arrays[sp["key"] + "_xy"], arrays[sp["key"] + "_rad"]
+    got = frame[torch.from_numpy(xy[:, 1].astype(np.int64)).cuda(), torch.from_numpy(xy[:, 0].astype(np.int64)).cuda()].cpu().numpy()
+    rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-3)
+    assert (rel <= 1e-4).all()
+    assert int((got.view(np.uint32) == want.view(np.uint32)).all(-1).sum()) >= len(xy) - 16
+
+
 def test_grid_search_equals_the_loop_over_every_sphere(torch_cuda, make_scene):
     """Big scenes search their spheres through a uniform grid (rt_kernels.hip: grid_walk).  For 300 000
     random rays - origins inside and outside the cloud, random and axis-parallel directions, and
