@@ -626,12 +626,15 @@ def test_c5_sparse_pins_tiled_scene(torch_cuda, golden, make_scene):
     ctx.close()
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("idx,cap", [(0, 1 << 22), (1, 1 << 24)])
-def test_rows_of_pins_of_the_sphere_clouds_at_full_size(torch_cuda, pins, make_scene, idx, cap):
+def test_rows_of_pins_of_the_sphere_clouds_at_full_size(torch_cuda, pins, make_scene, idx, cap, fused):
     """tests/golden/pins.npz: the reference's get_pixel_color on 64 rows x 512 pixels of config 4 (3840x2160, 16 spp,
     depth 8) and on 32 rows x 256 pixels of config 5 (7680x4320, 64 spp, depth 16, 16 384 spheres, 8 lights).  Each
     row is rendered as a band of the real frame; EVERY pin within 1e-4 (relative, floor 1e-3) and all but a handful
-    bit-identical with the reference's own float (libm's powf is faithfully, not correctly, rounded: section 2 of DESIGN.md)."""
+    bit-identical with the reference's own float (libm's powf is faithfully, not correctly, rounded: section 2 of DESIGN.md).
+    Once by the job pipeline (what these scenes get) and once by the fused kernels walking the grid
+    (rt_hip_ctx_set_pipeline: what instrumented renders of them run)."""
     torch = torch_cuda
     meta, arrays = pins
     sp = meta["pins"][idx]
@@ -640,6 +643,8 @@ def test_rows_of_pins_of_the_sphere_clouds_at_full_size(torch_cuda, pins, make_s
     cam = rt.prepare_camera(sc, W, H, sp["sqrtSpp"], sp["depth"])
     ctx = rt.Context(queue_cap=cap)
     ctx.upload(sc)
+    if fused:
+        ctx.set_pipeline(rt.PIPELINE_FUSED)
     xy, want = arrays[sp["key"] + "_xy"], arrays[sp["key"] + "_rad"]
     assert len(xy) == sp["rows"] * sp["per_row"] >= 8192
     argb = torch.zeros((H, W), dtype=torch.int32, device="cuda")
@@ -654,7 +659,7 @@ def test_rows_of_pins_of_the_sphere_clouds_at_full_size(torch_cuda, pins, make_s
         rel = np.abs(got - w) / np.maximum(np.abs(w), 1e-3)
         assert (rel <= 1e-4).all(), (int(y), xy[on][np.nonzero((rel > 1e-4).any(-1))[0][:4]].tolist())
         exact += int((got.view(np.uint32) == w.view(np.uint32)).all(-1).sum())
-    print(f"{sp['key']}: {exact} of {len(xy)} pins bit-identical")
+    print(f"{sp['key']}{' (fused)' if fused else ''}: {exact} of {len(xy)} pins bit-identical")
     assert exact >= len(xy) - 16  # measured: 32 767 of 32 768 and 8192 of 8192
     ctx.close()
 
