@@ -180,7 +180,9 @@ void raytrace(unsigned int *buffer, rt_scene_t *scene,
 /* north_star entry: render `fb` rows of `scene` seen through `camera` on the current HIP
  * device.  Host pointers in, host pixels out (H2D of the flattened scene, kernels, D2H).
  * Replaces the body of raytrace() after prepare_scene (raytrace.c:903-927).
- * Returns 0 or a negative hipError_t / RT_E_* code. */
+ * Returns 0 or a negative hipError_t / RT_E_* code.  The queues are the call's own business: a
+ * frame whose ray trees do not fit them even one tile row at a time is rendered again with four
+ * times the room, up to the default capacity (rt_hip_ctx_create), before RT_E_OVERFLOW is returned. */
 int rt_hip_render(const rt_scene *scene, const rt_camera *camera, rt_framebuffer *fb);
 
 /* The same blocking, host-pointer render spread over several GPUs of THIS process: device
