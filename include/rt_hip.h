@@ -222,7 +222,10 @@ int  rt_hip_ctx_create(rt_hip_ctx **out, int device, uint64_t max_queue_rays);
 void rt_hip_ctx_destroy(rt_hip_ctx *ctx);
 
 /* Flatten the AoS host scene (object3d_t[], pointlight_t[], polygon vertex lists --
- * the arrays the Cell build DMAs in spu/spu_main.c:54-148) into SoA device arrays. */
+ * the arrays the Cell build DMAs in spu/spu_main.c:54-148) into SoA device arrays.  Refused with RT_E_INVALID and
+ * a message (rt_hip_last_error), the context keeping the scene it had: polygon data beyond a block's LDS (some
+ * hundred quads), and - in scenes of more spheres than a block's LDS holds, which are searched through grids - a
+ * sphere or light whose coordinates are not finite or lie beyond 1e15. */
 int  rt_hip_scene_upload(rt_hip_ctx *ctx, const rt_scene *scene);
 
 /* Enqueue the render of rows [row0,row0+nrows) on `stream` (a hipStream_t, NULL = default

@@ -1837,6 +1837,26 @@ int rt_hip_scene_upload(rt_hip_ctx *c, const rt_scene *sc)
 
     std::vector<uint32_t> grid, lgrid;
     if (nSph > RT_TILE_SPHERES) {
+        /* The grid is built from the spheres' bounds and the light grids from the lights' positions: a centre, radius or
+         * position that is not a finite number (or lies beyond 1e15) has no cell (the reference's own arithmetic turns such a sphere into NaN
+         * comparisons; a small scene goes through the same arithmetic here, a searched one is refused). */
+        for (uint32_t k = 0; k < nSph; ++k) {
+            const float r = sc->objects[sph_obj[k]].sphr_obj.radius;
+            const float big = 1e15f; /* (squares of the grid's extent stay floats; the reference's own |o - c|^2 is inf at 1.8e19) */
+            if (!(fabsf(sph[k].x) <= big) || !(fabsf(sph[k].y) <= big) || !(fabsf(sph[k].z) <= big) || !(fabsf(r) <= big)) {
+                set_err("sphere object %u has a centre or radius that is not finite (or beyond 1e15): scenes of more than %d "
+                        "spheres are searched through a grid, which needs finite bounds", sph_obj[k], (int)RT_TILE_SPHERES);
+                return RT_E_INVALID;
+            }
+        }
+        for (uint32_t l = 0; l < nL; ++l) {
+            const rt_pointlight &L = sc->lights[l];
+            if (!(fabsf(L.position.x) <= 1e15f) || !(fabsf(L.position.y) <= 1e15f) || !(fabsf(L.position.z) <= 1e15f)) {
+                set_err("light %u has a position that is not finite (or beyond 1e15): scenes of more than %d spheres are searched through "
+                        "grids around their lights", l, (int)RT_TILE_SPHERES);
+                return RT_E_INVALID;
+            }
+        }
         std::vector<double> grown;
         double reach = 0.0;
         build_grid(sph, sc, sph_obj, grid, grown, reach);

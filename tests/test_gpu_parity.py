@@ -418,6 +418,41 @@ def test_a_scene_of_more_polygons_than_a_blocks_lds_holds_is_refused_at_upload(t
     ctx.close()
 
 
+def test_a_searched_scene_with_a_sphere_or_light_that_is_not_finite_is_refused_at_upload(torch_cuda, make_scene):
+    """Scenes of more spheres than a block's LDS holds are searched through grids built from the spheres' bounds and the
+    lights' positions: a NaN, an infinity or a coordinate beyond 1e15 has no cell there, and rt_hip_scene_upload says so
+    (the reference's own arithmetic makes NaN comparisons of such a sphere).  The context keeps the scene it had."""
+    sc = make_scene("c4")
+    cam = rt.prepare_camera(sc, 64, 40, 1, 3)
+    ctx = rt.Context(queue_cap=1 << 20)
+    ctx.upload(sc)
+    a0, r0, _ = render_dev(torch_cuda, ctx, cam)
+    o = sc.c.objects[17]
+    assert o.geometryType == 1
+    for field, value in [("x", float("nan")), ("y", float("inf")), ("z", -1e20)]:
+        keep = getattr(o.sphr_obj.center, field)
+        setattr(o.sphr_obj.center, field, value)
+        with pytest.raises(rt.RtHipError, match="sphere object 17 .* not finite"):
+            ctx.upload(sc)
+        setattr(o.sphr_obj.center, field, keep)
+    keep = o.sphr_obj.radius
+    o.sphr_obj.radius = float("inf")
+    with pytest.raises(rt.RtHipError, match="sphere object 17"):
+        ctx.upload(sc)
+    o.sphr_obj.radius = keep
+    keep = sc.c.lights[0].position.y
+    sc.c.lights[0].position.y = float("-inf")
+    with pytest.raises(rt.RtHipError, match="light 0 .* not finite"):
+        ctx.upload(sc)
+    sc.c.lights[0].position.y = keep
+    a1, r1, _ = render_dev(torch_cuda, ctx, cam)      # the scene of the first upload, untouched
+    assert np.array_equal(a0, a1) and np.array_equal(r0.view(np.uint32), r1.view(np.uint32))
+    ctx.upload(sc)                                    # ... and the restored one is taken again
+    a2, r2, _ = render_dev(torch_cuda, ctx, cam)
+    assert np.array_equal(a0, a2) and np.array_equal(r0.view(np.uint32), r2.view(np.uint32))
+    ctx.close()
+
+
 # ---------------------------------------------------------------------------------------------
 # device-resident interface
 # ---------------------------------------------------------------------------------------------
