@@ -172,6 +172,23 @@ __device__ __forceinline__ void normalize3(float &x, float &y, float &z)
 #endif
 }
 
+/* ... for a direction of ANY length: a transmission ray's is the incoming direction over the material's index
+ * (raytrace.c:455-457), and an index of 1e-30 makes its squares overflow - the reference then divides by an infinite
+ * length and pushes the origin by zero.  div_with alone gives NaN there (and for a length of zero): the hardware's
+ * fix-up restores the IEEE quotients, three instructions that only these rays pay. */
+__device__ __forceinline__ void normalize3_any(float &x, float &y, float &z)
+{
+#ifdef RT_FAST
+    normalize3(x, y, z);
+#else
+    const float m = mag3(x, y, z);
+    const float rm = rcp_refined(m);
+    x = __builtin_amdgcn_div_fixupf(div_with(x, m, rm), m, x);
+    y = __builtin_amdgcn_div_fixupf(div_with(y, m, rm), m, y);
+    z = __builtin_amdgcn_div_fixupf(div_with(z, m, rm), m, z);
+#endif
+}
+
 /* ray_create's length and its reciprocal (ray.c:34-37): mag = |d|, inv = 1.0f / mag */
 __device__ __forceinline__ void length_and_reciprocal(float dx, float dy, float dz, float &mag, float &inv)
 {
@@ -195,8 +212,12 @@ template <bool UNIT = false>
 __device__ __forceinline__ void tinypush(Ray &r)
 {
     float nx = r.dx, ny = r.dy, nz = r.dz;
-    if constexpr (!(kFast && UNIT))
-        normalize3(nx, ny, nz);
+    if constexpr (UNIT) {
+        if constexpr (!kFast)
+            normalize3(nx, ny, nz);
+    } else {
+        normalize3_any(nx, ny, nz);
+    }
     r.ox = r.ox + nx * 0.001f;
     r.oy = r.oy + ny * 0.001f;
     r.oz = r.oz + nz * 0.001f;

@@ -1317,6 +1317,39 @@ def test_big_scene_frames_against_the_reference(torch_cuda, make_scene, name):
     ctx.close()
 
 
+@pytest.mark.parametrize("name", ["builtin", "c4"])
+@pytest.mark.parametrize("index", [1e-30, 3e-19, 1e30, 0.0, -1.0])
+def test_refraction_indices_no_glass_has(torch_cuda, make_scene, name, index):
+    """A transmission ray's direction is the incoming one over the material's index (raytrace.c:455-457): an index of
+    1e-30 gives it a length whose square overflows, ray_tinypush then divides by an infinite length and moves the
+    origin by zero, and the ray still meets a polygon (at a distance of 1e-30 or so).  An index of 0 makes it NaN.  The
+    reference computes what IEEE arithmetic gives; so do the kernels (found by tools/fuzz_big.py, FUZZ_WILD=1): every
+    pixel bit-identical to the oracle, on the fused kernels (the reference's scene) and on the job pipeline (config 4's)."""
+    sc = make_scene(name)
+    glass = 0
+    for i in range(sc.c.nObjects):
+        m = sc.c.objects[i].material
+        if m.kt != 0.0:
+            m.n = index
+            glass += 1
+    assert glass
+    cam = rt.prepare_camera(sc, 128, 80, 2, 5)
+    ctx = rt.Context(queue_cap=1 << 21)
+    ctx.upload(sc)
+    argb, rad, st = render_dev(torch_cuda, ctx, cam)
+    ctx.close()
+    assert st.transmission_rays > 1000
+    O.set_rounded_pow(True)
+    try:
+        a_o, r_o, c_o = O.render(sc.c, cam, nthreads=16)
+    finally:
+        O.set_rounded_pow(False)
+    same = (rad.view(np.uint32) == r_o.view(np.uint32)) | (np.isnan(rad) & np.isnan(r_o))
+    assert same.all(), int((~same).any(-1).sum())
+    assert np.array_equal(argb, a_o)
+    assert st.transmission_rays == c_o["transmission_rays"] and st.shade_nodes == c_o["shade_nodes"]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_lights", [1, 3])
 def test_hits_beyond_the_grids_reach_take_the_loop_over_every_sphere(torch_cuda, tmp_path, n_lights):

@@ -2,6 +2,7 @@
 spheres, glass of index 0.8 / 0.95 / 1 / 1.25 (rays longer than unit: k_loop behind its groups' balls), mirrors, 0-4
 quads near and far, 1-8 lights (k_hits sends the shadow rays of one or two), the eye outside, inside and far from the
 cloud - GPU against the oracle with libm's powf rounding taken out: every pixel bit-identical.
+FUZZ_WILD=1: refraction indices of 0, -1, 1e-30, 1e30 and reflection / transmission coefficients below 0 and above 1.
 usage: python tools/fuzz_big.py [cases] [seed] [first case rendered]"""
 import sys, time, tempfile, os; sys.path.insert(0, '.')
 import numpy as np, raytracer_amd as rt
@@ -37,6 +38,9 @@ for c in range(cases):
         m = int(rng.integers(0, 4))
         kr, kt = [(0.0, 0.0), (0.5, 0.0), (0.05, 0.8), (0.3, 0.5)][m]
         n = float(rng.choice([0.8, 0.95, 1.0, 1.25]))
+        if os.environ.get("FUZZ_WILD"):  # indices and coefficients no material has: zero and negative indices, gains above one
+            n = float(rng.choice([0.0, -1.0, 1e-30, 1e30, 1e-12, 1e12, 1e-20, 3e-19, 0.5, 3.0, 1.0]))
+            kr, kt = float(rng.choice([0.0, -0.5, 1.5, 0.3])), float(rng.choice([0.0, -0.5, 2.0, 0.6]))
         parts.append("sphere\n{\nname S%d\nposition %r %r %r\nradius %r\ndiffuse %g %g %g\nspecular 1 1 1\n"
                      "ka 0.1 kd 0.4 ks 0.3 ke %d kr %g kt %g n %g\n}\n"
                      % (k, x, y, z, float(rng.uniform(0.02, rmax)), *rng.uniform(0.2, 1, 3), int(rng.choice([2, 20])), kr, kt, n))
@@ -98,8 +102,13 @@ for c in range(cases):
         bad += 1
     print("%s case %d: %dx%d s%d d%d sph=%d lights=%d quads=%d ext=%g eye-mode=%d differ=%d second-render-same=%s [%.0f s]%s"
           % ("ok " if ok and ok2 else "BAD", c, W, H, s, d, n_sph, n_l, n_pol, ext, mode, int(differ.sum()), ok2, time.time() - t0, extra if os.environ.get("FUZZ_CTX") else ""), flush=True)
-    if not ok and os.environ.get("FUZZ_CTX"):
+    if not ok:
         ys, xs = np.nonzero(differ)
         print("    differing pixels (y, x):", list(zip(ys.tolist(), xs.tolist()))[:12], flush=True)
+        for y, x in list(zip(ys.tolist(), xs.tolist()))[:4]:
+            print("    (%d, %d): GPU %r oracle %r" % (y, x, rad[y, x].tolist(), r_o[y, x].tolist()), flush=True)
+        if os.environ.get("FUZZ_DUMP"):
+            import shutil
+            shutil.copy(path, os.path.join(os.environ["FUZZ_DUMP"], "bad_case_%d.scene" % c))
 print("%d bad of %d" % (bad, cases))
 sys.exit(1 if bad else 0)
