@@ -1,7 +1,7 @@
 """development: random scenes / cameras / frame shapes, GPU against the oracle with libm's powf rounding
 taken out (rt_oracle_set_rounded_pow): every pixel's radiance must be bit-identical.
 usage: python tools/fuzz_parity.py [cases] [seed]"""
-import sys, time; sys.path.insert(0, '.')
+import os, sys, time; sys.path.insert(0, '.')
 import numpy as np, raytracer_amd as rt
 from oracle import oracle_py as O
 
@@ -29,13 +29,36 @@ for c in range(cases):
     if rng.random() < 0.5:   # move the eye: rays that start inside or behind objects
         sc.c.eyePos.x += float(rng.normal(0, 2)); sc.c.eyePos.y += float(rng.normal(0, 1)); sc.c.eyePos.z += float(rng.normal(0, 6))
         desc += f" eye=({sc.c.eyePos.x:.3f},{sc.c.eyePos.y:.3f},{sc.c.eyePos.z:.3f})"
+    if os.environ.get("FUZZ_WILD"):  # what no modeller would write: indices of 0 / -1 / 1e-30 / 1e30, gains outside [0, 1], exponents of 0
+        for i in range(sc.c.nObjects):   # and 1, negative colours, spheres of radius 0 or less, spheres twice, a sphere around the eye
+            o = sc.c.objects[i]; m = o.material
+            if rng.random() < 0.3:
+                m.n = float(rng.choice([0.0, -1.0, 1e-30, 1e30, 1e-12, 3e-19, 0.5, 3.0]))
+            if rng.random() < 0.2:
+                m.kr = float(rng.choice([-0.5, 1.5, 0.3])); m.kt = float(rng.choice([-0.5, 2.0, 0.6, 0.0]))
+            if rng.random() < 0.2:
+                m.phong_ke = float(rng.choice([0.0, 1.0, 3.0, 200.0]))
+            if rng.random() < 0.1:
+                m.colors[0].r = -0.5; m.colors[1].g = 3.0
+            if o.geometryType == 1:
+                u = rng.random()
+                if u < 0.05:
+                    o.sphr_obj.radius = 0.0
+                elif u < 0.1:
+                    o.sphr_obj.radius = -o.sphr_obj.radius
+                elif u < 0.15 and i > 0 and sc.c.objects[i - 1].geometryType == 1:
+                    q = sc.c.objects[i - 1].sphr_obj
+                    o.sphr_obj.center.x, o.sphr_obj.center.y, o.sphr_obj.center.z, o.sphr_obj.radius = q.center.x, q.center.y, q.center.z, q.radius
+                elif u < 0.17:
+                    o.sphr_obj.center.x, o.sphr_obj.center.y, o.sphr_obj.center.z = sc.c.eyePos.x, sc.c.eyePos.y, sc.c.eyePos.z
+        desc += " (wild)"
     big = cls == 3
     W, H = int(rng.integers(1, 40 if big else 110)), int(rng.integers(1, 30 if big else 80))
     s, d = int(rng.integers(1, 4)), int(rng.integers(0, 11))
     cam = rt.prepare_camera(sc, W, H, s, d)
     argb, rad = rt.render(sc, cam)
     a_o, r_o, _ = O.render(sc.c, cam, nthreads=16)
-    differ = (rad.view(np.uint32) != r_o.view(np.uint32)).any(-1)
+    differ = ((rad.view(np.uint32) != r_o.view(np.uint32)) & ~(np.isnan(rad) & np.isnan(r_o))).any(-1)
     tag = "ok " if not differ.any() and np.array_equal(argb, a_o) else "BAD"
     if tag == "BAD":
         bad += 1
