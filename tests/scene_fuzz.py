@@ -27,8 +27,9 @@ def random_polygon(rng, kind):
     return pts
 
 
-def random_scene_text(rng):
-    """-> (text of a scene file, list of polygon kinds)"""
+def random_scene_text(rng, cloud=0):
+    """-> (text of a scene file, list of polygon kinds); cloud > 0: that many small spheres on top, mirrors and glass
+    among them (the scene is then searched through a grid: the polygons meet the job pipeline)"""
     lines = ["camera", "{", f"position {rng.normal(0, 1):.4f} {rng.uniform(1, 5):.4f} {rng.uniform(0, 4):.4f}",
              f"lookat {rng.normal(0, 1):.4f} {rng.uniform(0, 3):.4f} -8", "upvector 0 1 0", "projection 45.0 1.0 200.0", "}",
              "world", "{", "ambient 0.7 0.7 0.8", "background 0.1 0.1 0.3", "}"]
@@ -44,4 +45,7 @@ def random_scene_text(rng):
     for _ in range(int(rng.integers(0, 4))):
         lines.append(f"sphere {{ name s position {rng.normal(0, 3):.3f} {rng.uniform(0, 4):.3f} {rng.uniform(-14, -4):.3f} radius {rng.uniform(0.4, 1.6):.3f} "
                      f"diffuse 0.9 0.9 0.9 ka 0.1 kd 0.4 ks 0.5 ke 20 kr {rng.choice([0, 0.5])} kt {rng.choice([0, 0.7])} n 1.3 }}")
+    for _ in range(cloud):
+        lines.append(f"sphere {{ name c position {rng.normal(0, 4):.3f} {rng.uniform(0, 5):.3f} {rng.uniform(-16, -2):.3f} radius {rng.uniform(0.05, 0.5):.3f} "
+                     f"diffuse 0.6 0.9 0.7 ka 0.1 kd 0.4 ks 0.5 ke 20 kr {rng.choice([0, 0, 0.5])} kt {rng.choice([0, 0, 0.7])} n {rng.choice([1.3, 0.9])} }}")
     return "\n".join(lines) + "\n", kinds

@@ -1,6 +1,7 @@
 """development: random scene FILES with arbitrary polygons (tests/scene_fuzz.py) through rt_load_scene; GPU
 against the oracle with libm's powf rounding taken out: every pixel bit-identical.  Exercises the
 three-stage polygon test (edge-screen data for any plane, unscreenable polygons).
+FUZZ_CLOUD=1: 130-600 small spheres on top (a grid, the job pipeline).
 usage: python tools/fuzz_polygons.py [cases] [seed]"""
 import os, sys, tempfile, time; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np, raytracer_amd as rt
@@ -14,7 +15,7 @@ tmp = tempfile.mkdtemp()
 bad, cover = 0, []
 t0 = time.time()
 for case in range(cases):
-    text, kinds = random_scene_text(rng)
+    text, kinds = random_scene_text(rng, cloud=int(rng.choice([130, 250, 600])) if os.environ.get("FUZZ_CLOUD") else 0)
     path = os.path.join(tmp, f"s{case}.scene")
     open(path, "w").write(text)
     sc = rt.load_scene(path)
