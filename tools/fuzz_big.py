@@ -2,7 +2,7 @@
 spheres, glass of index 0.8 / 0.95 / 1 / 1.25 (rays longer than unit: k_loop behind its groups' balls), mirrors, 0-4
 quads near and far, 1-8 lights (k_hits sends the shadow rays of one or two), the eye outside, inside and far from the
 cloud - GPU against the oracle with libm's powf rounding taken out: every pixel bit-identical.
-FUZZ_WILD=1: refraction indices of 0, -1, 1e-30, 1e30 and reflection / transmission coefficients below 0 and above 1.
+FUZZ_DEVICES=1: through rt_hip_render_devices, 1-5 shares of one GPU.  FUZZ_WILD=1: refraction indices of 0, -1, 1e-30, 1e30 and reflection / transmission coefficients below 0 and above 1.
 usage: python tools/fuzz_big.py [cases] [seed] [first case rendered]"""
 import sys, time, tempfile, os; sys.path.insert(0, '.')
 import numpy as np, raytracer_amd as rt
@@ -84,6 +84,8 @@ for c in range(cases):
                 a_, r_, st_ = render_dev(torch, ctx, cam, r0, r1 - r0)
                 argb[r0:r1] = a_[r0:r1]; rad[r0:r1] = r_[r0:r1]
             ctx.close()
+        elif os.environ.get("FUZZ_DEVICES"):  # rt_hip_render_devices: the frame's 8-row blocks dealt to 1-5 shares of this box's one GPU
+            argb, rad = rt.render(sc, cam, devices=[0] * int(rng.integers(1, 6)))
         else:
             argb, rad = rt.render(sc, cam)
     except rt.RtHipError as e:
@@ -96,7 +98,7 @@ for c in range(cases):
     a_o, r_o, _ = O.render(sc.c, cam, nthreads=16)
     differ = (rad.view(np.uint32) != r_o.view(np.uint32)).any(-1)
     ok = not differ.any() and np.array_equal(argb, a_o)
-    argb2, rad2 = (argb, rad) if os.environ.get("FUZZ_CTX") else rt.render(sc, cam)
+    argb2, rad2 = (argb, rad) if os.environ.get("FUZZ_CTX") else rt.render(sc, cam)  # (the second render: one device, whatever the first was)
     ok2 = np.array_equal(argb2, argb) and np.array_equal(rad2.view(np.uint32), rad.view(np.uint32))
     if not (ok and ok2):
         bad += 1
