@@ -56,7 +56,16 @@ for c in range(cases):
     W, H = int(rng.integers(1, 40 if big else 110)), int(rng.integers(1, 30 if big else 80))
     s, d = int(rng.integers(1, 4)), int(rng.integers(0, 11))
     cam = rt.prepare_camera(sc, W, H, s, d)
-    argb, rad = rt.render(sc, cam)
+    if os.environ.get("FUZZ_BLINN"):  # the reference's unused second shading routine (rt_hip_ctx_set_shading)
+        import torch
+        sys.path.insert(0, "tests")
+        from test_gpu_parity import render_dev
+        ctx = rt.Context(); ctx.upload(sc); ctx.set_shading(rt.SHADE_PHONGBLINN)
+        argb, rad, _ = render_dev(torch, ctx, cam)
+        ctx.close()
+        O.set_shading(1)
+    else:
+        argb, rad = rt.render(sc, cam)
     a_o, r_o, _ = O.render(sc.c, cam, nthreads=16)
     differ = ((rad.view(np.uint32) != r_o.view(np.uint32)) & ~(np.isnan(rad) & np.isnan(r_o))).any(-1)
     tag = "ok " if not differ.any() and np.array_equal(argb, a_o) else "BAD"
