@@ -21,6 +21,7 @@ def work(t):
         cam = rt.prepare_camera(sc, W, H, s, d)
         ctx = rt.Context(); ctx.upload(sc)
         argb = torch.zeros((H, W), dtype=torch.int32, device="cuda"); rad = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+        st.wait_stream(torch.cuda.current_stream())  # (the fills above ran on torch's current stream, not on st)
         for _ in range(3):   # (the third frame of a small scene may run kernels compiled for it meanwhile)
             ctx.render_rows(cam, argb.data_ptr(), rad.data_ptr(), 0, H, st.cuda_stream); ctx.finish()
         st.synchronize()
